@@ -1,0 +1,182 @@
+"""Generate the golden fixtures under tests/golden/ from the REAL reference model.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container, where the reference
+checkout is mounted read-only at /root/reference:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+The reference (pure PyTorch) is imported, never copied; it cannot travel to the
+GPU box, so its inputs/outputs/gradients are committed as small .npz fixtures:
+
+  tiny_default.npz / tiny_trained.npz
+      a small DSTformer (C=64, 2 heads of 32, depth 2, T=9) with every weight,
+      the input, the output, the representation, a random cotangent and the
+      reference autograd gradient of every parameter and of the input (fp64).
+  seed0_lite.npz / seed0_full.npz
+      MotionBERT-Lite / full model exactly as `load_backbone` builds them
+      (lib/utils/learning.py:83-85) after torch.manual_seed(0): per-parameter
+      (sum, |sum|) of the initial weights, a [1,27,17,3] input, the fp64 output
+      and per-parameter (l2, sum) of the gradients.  The weights themselves are
+      re-created on the test machine from the same seed.
+
+While generating, the numpy oracle is checked against the reference (fp64
+forward and every gradient); the script aborts if they disagree.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from functools import partial
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get('MOTIONBERT_REFERENCE', '/root/reference')
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import dstformer_oracle as O
+
+
+def import_reference():
+    """Import the reference class without shadowing by this repo's own lib/ shim."""
+    import importlib.util
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'lib' or k.startswith('lib.')}
+    sys.path.insert(0, REF)
+    try:
+        spec = importlib.util.spec_from_file_location('ref_lib_model_drop', os.path.join(REF, 'lib/model/drop.py'))
+        drop = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(drop)
+        # DSTformer.py does `from lib.model.drop import DropPath`
+        import types
+        lib = types.ModuleType('lib'); lib.__path__ = [os.path.join(REF, 'lib')]
+        libm = types.ModuleType('lib.model'); libm.__path__ = [os.path.join(REF, 'lib/model')]
+        sys.modules.update({'lib': lib, 'lib.model': libm, 'lib.model.drop': drop})
+        spec = importlib.util.spec_from_file_location('lib.model.DSTformer', os.path.join(REF, 'lib/model/DSTformer.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.DSTformer
+    finally:
+        sys.path.remove(REF)
+        for k in [k for k in sys.modules if k == 'lib' or k.startswith('lib.')]:
+            sys.modules.pop(k)
+        sys.modules.update(saved)
+
+
+def make_input(B, T, J, seed):
+    """Synthetic 2D keypoints: x,y ~ U(-1,1), confidence ~ U(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(B, T, J, 2, generator=g) * 2 - 1
+    conf = torch.rand(B, T, J, 1, generator=g)
+    return torch.cat([xy, conf], -1)
+
+
+def trained_like(model, seed):
+    """Perturb default init so softmaxes are not flat and the fusion is data dependent."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith('ts_attn'):
+                p.add_(torch.randn(p.shape, generator=g) * (0.05 if p.ndim == 2 else 0.2))
+            elif p.ndim >= 2 and 'embed' not in n:
+                p.mul_(3.0)
+            elif 'norm' in n and n.endswith('weight'):
+                p.add_(torch.randn(p.shape, generator=g) * 0.2)
+            elif n.endswith('bias'):
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+
+
+def run_reference(model, x, cot, return_rep=False):
+    m = model.double()
+    xd = x.double().requires_grad_(True)
+    out = m(xd, return_rep=return_rep)
+    rep = m.get_representation(xd).detach()
+    (out * cot.double()).sum().backward()
+    grads = {n: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().copy() for n, p in m.named_parameters()}
+    return out.detach().numpy(), rep.numpy(), grads, xd.grad.numpy().copy()
+
+
+def check_oracle(cfg, sd, x, cot, out_ref, grads_ref, dx_ref, tag):
+    out, cache = O.forward(sd, x, cfg, want_cache=True)
+    e = O.rel_l2(out, out_ref)
+    G, dx = O.backward(sd, cache, cot, cfg)
+    worst = max(O.rel_l2(G[k], grads_ref[k]) if np.linalg.norm(grads_ref[k]) > 0 else float(np.abs(G[k]).max()) for k in grads_ref)
+    edx = O.rel_l2(dx, dx_ref)
+    print(f'[{tag}] oracle vs reference(fp64): out {e:.2e}  worst-grad {worst:.2e}  dx {edx:.2e}')
+    assert e < 1e-10 and worst < 1e-8 and edx < 1e-9, 'oracle disagrees with the reference'
+    assert set(G) == set(grads_ref), (set(G) ^ set(grads_ref))
+
+
+def tiny(DST, variant):
+    kw = dict(dim_in=3, dim_out=3, dim_feat=64, dim_rep=64, depth=2, num_heads=2, mlp_ratio=2,
+              num_joints=17, maxlen=16)
+    torch.manual_seed(1234)
+    model = DST(norm_layer=partial(nn.LayerNorm, eps=1e-6), **kw)
+    if variant == 'trained':
+        trained_like(model, 99)
+    B, T = 2, 9
+    x = make_input(B, T, 17, 7)
+    cot = torch.randn(B, T, 17, 3, generator=torch.Generator().manual_seed(8))
+    sd32 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+    out, rep, grads, dx = run_reference(model, x, cot)
+    cfg = O.OracleConfig(eps=1e-6, **kw)
+    check_oracle(cfg, sd32, x.numpy(), cot.numpy(), out, grads, dx, f'tiny_{variant}')
+    # representation-path gradients (ActionNet path, model_action.py:68): head gets no gradient
+    cot_rep = torch.randn(B, T, 17, 64, generator=torch.Generator().manual_seed(9))
+    model.zero_grad()
+    out_r, _, grads_r, dx_r = run_reference(model, x, cot_rep, return_rep=True)
+    o2, cache = O.forward(sd32, x.numpy(), cfg, return_rep=True, want_cache=True)
+    G2, dx2 = O.backward(sd32, cache, cot_rep.numpy(), cfg, return_rep=True)
+    assert O.rel_l2(o2, out_r) < 1e-10 and O.rel_l2(dx2, dx_r) < 1e-9
+    assert max(O.rel_l2(G2[k], grads_r[k]) for k in grads_r if np.linalg.norm(grads_r[k]) > 0) < 1e-8
+    save = dict(x=x.numpy(), cot=cot.numpy(), out=out, rep=rep, dx=dx,
+                cot_rep=cot_rep.numpy(), dx_rep=dx_r)
+    save.update({f'cfg.{k}': np.asarray(v) for k, v in kw.items()})
+    save.update({f'w.{k}': v for k, v in sd32.items()})
+    save.update({f'g.{k}': v.astype(np.float32) for k, v in grads.items()})
+    save.update({f'grep.{k}': v.astype(np.float32) for k, v in grads_r.items()})
+    np.savez_compressed(os.path.join(ROOT, 'tests/golden', f'tiny_{variant}.npz'), **save)
+
+
+def seeded(DST, name, dim_feat, mlp_ratio):
+    kw = dict(dim_in=3, dim_out=3, dim_feat=dim_feat, dim_rep=512, depth=5, num_heads=8, mlp_ratio=mlp_ratio,
+              num_joints=17, maxlen=243)
+    torch.manual_seed(0)  # train.py:37,41-44 default seed
+    model = DST(norm_layer=partial(nn.LayerNorm, eps=1e-6), **kw)
+    sd32 = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+    nparam = sum(v.size for v in sd32.values())
+    B, T = 1, 27
+    x = make_input(B, T, 17, 11)
+    cot = torch.randn(B, T, 17, 3, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        out32 = model(x).numpy().copy()
+    out, rep, grads, dx = run_reference(model, x, cot)
+    cfg = O.OracleConfig(eps=1e-6, **kw)
+    check_oracle(cfg, sd32, x.numpy(), cot.numpy(), out, grads, dx, name)
+    names = list(sd32.keys())
+    save = dict(x=x.numpy(), cot=cot.numpy(), out=out, out_fp32=out32, dx=dx, nparam=np.asarray(nparam),
+                names=np.asarray(names),
+                w_stats=np.asarray([[sd32[k].astype(np.float64).sum(), np.abs(sd32[k].astype(np.float64)).sum()] for k in names]),
+                g_stats=np.asarray([[np.linalg.norm(grads[k]), grads[k].sum()] for k in names]),
+                rep_stats=np.asarray([np.linalg.norm(rep), rep.sum()]))
+    save.update({f'cfg.{k}': np.asarray(v) for k, v in kw.items()})
+    np.savez_compressed(os.path.join(ROOT, 'tests/golden', f'seed0_{name}.npz'), **save)
+    print(f'[{name}] params {nparam:,}; fp32-vs-fp64 output rel-l2 {O.rel_l2(out32, out):.2e}')
+
+
+def main():
+    assert os.path.isdir(REF), f'reference checkout not found at {REF}'
+    DST = import_reference()
+    os.makedirs(os.path.join(ROOT, 'tests/golden'), exist_ok=True)
+    tiny(DST, 'default')
+    tiny(DST, 'trained')
+    seeded(DST, 'lite', 256, 4)
+    seeded(DST, 'full', 512, 2)
+    print('golden fixtures written')
+
+
+if __name__ == '__main__':
+    main()
