@@ -1,0 +1,271 @@
+"""Host-side sequencing of the DSTformer hot path over the HIP kernel set.
+
+This module owns no arithmetic.  It walks the dual-stream block structure of
+the reference model (`lib/model/DSTformer.py:329-358` forward, `:239-249`
+Block) and issues one call per kernel on an `ops` object whose methods map
+1:1 onto the C-ABI entry points declared in `include/mbx.h`.  The product
+`ops` is `motionbert_amd.hip_ops.HipOps` (ctypes -> libmbx.so -> gfx950
+kernels); there is no CPU implementation in the package.
+
+Data layout in HBM (all row-major, token index m = (b*T + t)*J + j):
+  residual stream   [M, C]  fp32   one fresh buffer per sub-layer output
+  GEMM operands     [M, K]  T      T = compute dtype (bf16 or fp32)
+  qkv               [M, 3C] T      channel order [3][H][hd]  (DSTformer.py:143)
+  attention out     [M, C]  T      heads concatenated head-major
+  softmax stats     [M, H]  fp32   log-sum-exp per (token, head)
+  LN stats          [M]     fp32   mean, rstd
+The temporal attention reads its (b, j, h) sequences straight out of the
+[B, T, J, 3C] qkv tensor with a row stride of J*3C elements: the three
+permute->contiguous copies of `DSTformer.py:190-192` do not exist here.
+
+What is saved for backward (per sub-layer): the fp32 sub-layer input, LN
+mean/rstd, the normalised T-typed GEMM input, and qkv/o/lse (attention) or
+the pre-/post-GELU hidden (MLP).  Attention probabilities are never stored:
+the backward kernels recompute them from q, k and lse.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import torch
+
+# GEMM epilogues (values mirror enum mbx_epilogue in include/mbx.h)
+EPI_STORE = 0      # out_t  = acc + bias                      (T)
+EPI_GELU = 1       # out_t  = acc + bias ; out2_t = gelu(out) (T, T)
+EPI_RESID = 2      # out_f  = resid + acc + bias              (fp32)
+EPI_TANH = 3       # out_f  = tanh(acc + bias)                (fp32)
+EPI_DGELU = 4      # out_t  = acc * gelu'(aux_t)              (T)
+
+MODE_SPATIAL = 0
+MODE_TEMPORAL = 1
+
+
+@dataclass(frozen=True)
+class ModelCfg:
+    dim_in: int
+    dim_out: int
+    C: int          # dim_feat
+    R: int          # dim_rep
+    depth: int
+    H: int
+    hidden: int
+    J: int
+    maxlen: int
+    eps: float
+    scale: float
+    att_fuse: bool
+    qkv_bias: bool
+
+    @property
+    def hd(self) -> int:
+        return self.C // self.H
+
+
+# sub-layer order of the two Block flavours (DSTformer.py:240-249)
+ORDER = {
+    'st': (('attn', 'norm1_s', 'attn_s', MODE_SPATIAL), ('mlp', 'norm2_s', 'mlp_s', None),
+           ('attn', 'norm1_t', 'attn_t', MODE_TEMPORAL), ('mlp', 'norm2_t', 'mlp_t', None)),
+    'ts': (('attn', 'norm1_t', 'attn_t', MODE_TEMPORAL), ('mlp', 'norm2_t', 'mlp_t', None),
+           ('attn', 'norm1_s', 'attn_s', MODE_SPATIAL), ('mlp', 'norm2_s', 'mlp_s', None)),
+}
+
+
+def linear_names(cfg: ModelCfg) -> List[str]:
+    """Every nn.Linear whose weight runs through the MFMA GEMM (prefix without '.weight')."""
+    names = []
+    for stream in ('blocks_st', 'blocks_ts'):
+        for i in range(cfg.depth):
+            for a in ('attn_s', 'attn_t'):
+                names += [f'{stream}.{i}.{a}.qkv', f'{stream}.{i}.{a}.proj']
+            for m in ('mlp_s', 'mlp_t'):
+                names += [f'{stream}.{i}.{m}.fc1', f'{stream}.{i}.{m}.fc2']
+    names.append('pre_logits.fc')
+    return names
+
+
+class Engine:
+    """One forward (and optionally backward) pass.  `P` maps reference state_dict
+    names to fp32 device tensors; `Wn[name]` / `Wt[name]` are the T-typed [N,K]
+    and transposed [K,N] copies produced by ops.prep_weights."""
+
+    def __init__(self, ops, cfg: ModelCfg, P: Dict[str, torch.Tensor], tdtype: torch.dtype):
+        self.ops, self.cfg, self.P, self.T = ops, cfg, P, tdtype
+        self.Wn: Dict[str, torch.Tensor] = {}
+        self.Wt: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _f(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def _t(self, *shape):
+        return torch.empty(shape, dtype=self.T, device=self.dev)
+
+    def _bias(self, name):
+        return self.P.get(name + '.bias')
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, return_rep: bool, need_grad: bool):
+        cfg, ops, P = self.cfg, self.ops, self.P
+        self.dev = x.device
+        B, T, J, Din = x.shape
+        M, C = B * T * J, cfg.C
+        self.B, self.Tlen, self.M = B, T, M
+        self.Wn, self.Wt = ops.prep_weights(P, linear_names(cfg), self.T, need_grad)
+        h = self._f(M, C)
+        ops.embed_fwd(x, P['joints_embed.weight'], P['joints_embed.bias'], P['pos_embed'], P['temp_embed'], h, B, T, J)
+        saved: Dict[str, Any] = dict(x=x, levels=[], return_rep=return_rep)
+        for i in range(cfg.depth):
+            x_st, sv_st = self._block_fwd(h, f'blocks_st.{i}', 'st', need_grad)
+            x_ts, sv_ts = self._block_fwd(h, f'blocks_ts.{i}', 'ts', need_grad)
+            hn = self._f(M, C)
+            if cfg.att_fuse:
+                alpha = self._f(M, 2)
+                ops.fuse_fwd(x_st, x_ts, P[f'ts_attn.{i}.weight'], P[f'ts_attn.{i}.bias'], hn, alpha)
+            else:
+                alpha = None
+                ops.average(x_st, x_ts, hn)
+            if need_grad:
+                saved['levels'].append(dict(st=sv_st, ts=sv_ts, x_st=x_st, x_ts=x_ts, alpha=alpha))
+            h = hn
+        xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+        ops.layernorm_fwd(h, P['norm.weight'], P['norm.bias'], cfg.eps, xn, mean, rstd)
+        rep = self._f(M, cfg.R)
+        ops.gemm_nt(xn, self.Wn['pre_logits.fc'], P['pre_logits.fc.bias'], EPI_TANH, out_f=rep)
+        if need_grad:
+            saved.update(h=h, xn=xn, mean=mean, rstd=rstd, rep=rep)
+        if return_rep:
+            out = rep.view(B, T, J, cfg.R)
+        else:
+            out = self._f(M, cfg.dim_out)
+            ops.head_fwd(rep, P['head.weight'], P['head.bias'], out)
+            out = out.view(B, T, J, cfg.dim_out)
+        return out, saved
+
+    def _block_fwd(self, x, pre, kind, need_grad):
+        svs = []
+        for typ, norm, mod, mode in ORDER[kind]:
+            if typ == 'attn':
+                x, sv = self._attn_fwd(x, pre, norm, mod, mode, need_grad)
+            else:
+                x, sv = self._mlp_fwd(x, pre, norm, mod, need_grad)
+            svs.append(sv)
+        return x, svs
+
+    def _attn_fwd(self, x, pre, norm, attn, mode, need_grad):
+        cfg, ops, P = self.cfg, self.ops, self.P
+        M, C = self.M, cfg.C
+        xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+        ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
+        qkv = self._t(M, 3 * C)
+        ops.gemm_nt(xn, self.Wn[f'{pre}.{attn}.qkv'], self._bias(f'{pre}.{attn}.qkv'), EPI_STORE, out_t=qkv)
+        o, lse = self._t(M, C), self._f(M, cfg.H)
+        ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
+        y = self._f(M, C)
+        ops.gemm_nt(o, self.Wn[f'{pre}.{attn}.proj'], P[f'{pre}.{attn}.proj.bias'], EPI_RESID, resid=x, out_f=y)
+        sv = dict(x=x, mean=mean, rstd=rstd, xn=xn, qkv=qkv, o=o, lse=lse) if need_grad else None
+        return y, sv
+
+    def _mlp_fwd(self, x, pre, norm, mlp, need_grad):
+        cfg, ops, P = self.cfg, self.ops, self.P
+        M, C = self.M, cfg.C
+        xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+        ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
+        u, g = self._t(M, cfg.hidden), self._t(M, cfg.hidden)
+        ops.gemm_nt(xn, self.Wn[f'{pre}.{mlp}.fc1'], P[f'{pre}.{mlp}.fc1.bias'], EPI_GELU, out_t=u, out2_t=g)
+        y = self._f(M, C)
+        ops.gemm_nt(g, self.Wn[f'{pre}.{mlp}.fc2'], P[f'{pre}.{mlp}.fc2.bias'], EPI_RESID, resid=x, out_f=y)
+        sv = dict(x=x, mean=mean, rstd=rstd, xn=xn, u=u, g=g) if need_grad else None
+        return y, sv
+
+    # ----------------------------------------------------------------- backward
+    def backward(self, saved, dout: torch.Tensor, grads: Dict[str, torch.Tensor], want_dx: bool):
+        """Fills `grads[name]` (fp32, pre-allocated, same shapes as the parameters) and
+        returns d(input) or None.  `dout` is d(out) with the shape `forward` returned."""
+        cfg, ops, P = self.cfg, self.ops, self.P
+        M, C, R = self.M, cfg.C, cfg.R
+        B, T, J = self.B, self.Tlen, cfg.J
+        G = self.grads = grads
+        dpre = self._t(M, R)
+        if saved['return_rep']:
+            ops.tanh_bwd(dout.reshape(M, R), saved['rep'], dpre)
+            if 'head.weight' in G:
+                G['head.weight'].zero_()
+                G['head.bias'].zero_()
+        else:
+            ops.head_bwd(dout.reshape(M, cfg.dim_out), saved['rep'], P['head.weight'], dpre,
+                         G['head.weight'], G['head.bias'])
+        dxn = self._t(M, C)
+        ops.gemm_nt(dpre, self.Wt['pre_logits.fc'], None, EPI_STORE, out_t=dxn)
+        ops.gemm_tn(dpre, saved['xn'], G['pre_logits.fc.weight'], G['pre_logits.fc.bias'])
+        dh = self._f(M, C)
+        ops.layernorm_bwd(dxn, saved['h'], saved['mean'], saved['rstd'], P['norm.weight'],
+                          None, None, dh, None, G['norm.weight'], G['norm.bias'])
+        del dxn, dpre
+        for i in reversed(range(cfg.depth)):
+            lv = saved['levels'][i]
+            d_st, d_ts = self._f(M, C), self._f(M, C)
+            d_st_t, d_ts_t = self._t(M, C), self._t(M, C)
+            if cfg.att_fuse:
+                ops.fuse_bwd(dh, lv['x_st'], lv['x_ts'], lv['alpha'], P[f'ts_attn.{i}.weight'],
+                             d_st, d_ts, d_st_t, d_ts_t, G[f'ts_attn.{i}.weight'], G[f'ts_attn.{i}.bias'])
+            else:
+                ops.average_bwd(dh, d_st, d_ts, d_st_t, d_ts_t)
+            d1, _ = self._block_bwd(d_st, d_st_t, lv['st'], f'blocks_st.{i}', 'st', None, last_needs_t=False)
+            del d_st, d_st_t
+            # the second stream's last LN-backward also adds the first stream's input gradient
+            dh, _ = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', d1, last_needs_t=False)
+            del d_ts, d_ts_t, d1
+            saved['levels'][i] = None  # release this level's activations
+        dx = torch.empty_like(saved['x']) if want_dx else None
+        ops.embed_bwd(dh, saved['x'], P['joints_embed.weight'], G['joints_embed.weight'], G['joints_embed.bias'],
+                      G['pos_embed'], G['temp_embed'], dx, B, T, J)
+        return dx
+
+    def _block_bwd(self, dy, dy_t, svs, pre, kind, extra_last, last_needs_t):
+        order = ORDER[kind]
+        for idx in reversed(range(4)):
+            typ, norm, mod, mode = order[idx]
+            extra = extra_last if idx == 0 else None
+            need_t = True if idx > 0 else last_needs_t
+            if typ == 'attn':
+                dy, dy_t = self._attn_bwd(dy, dy_t, svs[idx], pre, norm, mod, mode, extra, need_t)
+            else:
+                dy, dy_t = self._mlp_bwd(dy, dy_t, svs[idx], pre, norm, mod, extra, need_t)
+            svs[idx] = None
+        return dy, dy_t
+
+    def _attn_bwd(self, dy, dy_t, sv, pre, norm, attn, mode, extra, need_t):
+        cfg, ops, P, G = self.cfg, self.ops, self.P, self.grads
+        M, C = self.M, cfg.C
+        do = self._t(M, C)
+        ops.gemm_nt(dy_t, self.Wt[f'{pre}.{attn}.proj'], None, EPI_STORE, out_t=do)
+        ops.gemm_tn(dy_t, sv['o'], G[f'{pre}.{attn}.proj.weight'], G[f'{pre}.{attn}.proj.bias'])
+        dqkv = self._t(M, 3 * C)
+        ops.attn_bwd(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
+        del do
+        dxn = self._t(M, C)
+        ops.gemm_nt(dqkv, self.Wt[f'{pre}.{attn}.qkv'], None, EPI_STORE, out_t=dxn)
+        ops.gemm_tn(dqkv, sv['xn'], G[f'{pre}.{attn}.qkv.weight'], G.get(f'{pre}.{attn}.qkv.bias'))
+        del dqkv
+        dx = self._f(M, C)
+        dx_t = self._t(M, C) if need_t else None
+        ops.layernorm_bwd(dxn, sv['x'], sv['mean'], sv['rstd'], P[f'{pre}.{norm}.weight'], dy, extra,
+                          dx, dx_t, G[f'{pre}.{norm}.weight'], G[f'{pre}.{norm}.bias'])
+        return dx, dx_t
+
+    def _mlp_bwd(self, dy, dy_t, sv, pre, norm, mlp, extra, need_t):
+        cfg, ops, P, G = self.cfg, self.ops, self.P, self.grads
+        M, C = self.M, cfg.C
+        du = self._t(M, cfg.hidden)
+        ops.gemm_nt(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], None, EPI_DGELU, out_t=du, aux_t=sv['u'])
+        ops.gemm_tn(dy_t, sv['g'], G[f'{pre}.{mlp}.fc2.weight'], G[f'{pre}.{mlp}.fc2.bias'])
+        dxn = self._t(M, C)
+        ops.gemm_nt(du, self.Wt[f'{pre}.{mlp}.fc1'], None, EPI_STORE, out_t=dxn)
+        ops.gemm_tn(du, sv['xn'], G[f'{pre}.{mlp}.fc1.weight'], G[f'{pre}.{mlp}.fc1.bias'])
+        del du
+        dx = self._f(M, C)
+        dx_t = self._t(M, C) if need_t else None
+        ops.layernorm_bwd(dxn, sv['x'], sv['mean'], sv['rstd'], P[f'{pre}.{norm}.weight'], dy, extra,
+                          dx, dx_t, G[f'{pre}.{norm}.weight'], G[f'{pre}.{norm}.bias'])
+        return dx, dx_t

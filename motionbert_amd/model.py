@@ -1,0 +1,245 @@
+"""Drop-in replacement for `lib.model.DSTformer.DSTformer` backed by HIP kernels.
+
+Boundary: the reference exposes the hot path as a Python class;
+its callers (`lib/utils/learning.py:79-85` load_backbone, `train.py:174`,
+`infer_wild.py:75-80`, `lib/model/model_action.py:68`) construct it, call
+`model(x)` / `model.get_representation(x)`, wrap it in `nn.DataParallel` and
+`load_state_dict(strict=True)` into it.  This class keeps
+
+  * the constructor signature and defaults of `DSTformer.py:270-273`,
+  * `forward(x, return_rep=False)` (`:329`), `get_representation` (`:360`),
+    `get_classifier` / `reset_classifier` (`:322-327`),
+  * the exact parameter tree, i.e. the 260 `state_dict` keys, shapes and order,
+  * the initialisation (same RNG consumption order, so the same seed yields
+    the same weights as the reference),
+
+and replaces the arithmetic: forward and backward run as hand-written gfx950
+kernels reached through the C ABI of `libmbx.so` (see `include/mbx.h`).
+The sub-modules below (`MLP`, `Attention`, `Block`) are parameter containers
+only; they carry no torch arithmetic and cannot be called.  There is no CPU
+path: calling the model on a non-ROCm tensor raises.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine, ModelCfg
+
+_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32}
+
+
+def _trunc_normal_(t, std):
+    # same sampling recipe as the reference helper (DSTformer.py:12-66): inverse-CDF
+    # truncated normal on [-2, 2]; torch ships the identical routine.
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+class _Holder(nn.Module):
+    """Parameter container; the fused HIP path does the math."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f'{type(self).__name__} is a parameter container of the fused HIP DSTformer; '
+                           'call the DSTformer module instead')
+
+
+class MLP(_Holder):
+    """fc1 -> GELU(erf) -> fc2  (DSTformer.py:69-85)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(_Holder):
+    """qkv + proj of one attention sub-layer (DSTformer.py:88-107).  Only the 'spatial'
+    and 'temporal' modes are ever built by Block (`:223-226`)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., st_mode='vanilla'):
+        super().__init__()
+        if st_mode not in ('spatial', 'temporal'):
+            raise NotImplementedError(f"Attention mode '{st_mode}' is dead code in the reference and not part of the hot path")
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)       # registered before qkv, as in the reference (RNG order)
+        self.mode = st_mode
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class Block(_Holder):
+    """Four pre-norm residual sub-layers (DSTformer.py:214-249)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., mlp_out_ratio=1., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, st_mode='stage_st', att_fuse=False):
+        super().__init__()
+        if st_mode not in ('stage_st', 'stage_ts'):
+            raise NotImplementedError(f"Block mode '{st_mode}' is never instantiated by DSTformer")
+        if att_fuse or mlp_out_ratio != 1.:
+            raise NotImplementedError('Block.att_fuse / mlp_out_ratio are unused by DSTformer')
+        self.st_mode = st_mode
+        self.norm1_s = norm_layer(dim)
+        self.norm1_t = norm_layer(dim)
+        self.attn_s = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                attn_drop=attn_drop, proj_drop=drop, st_mode='spatial')
+        self.attn_t = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                attn_drop=attn_drop, proj_drop=drop, st_mode='temporal')
+        self.drop_path = nn.Identity()
+        self.drop_path_rate = float(drop_path)
+        self.norm2_s = norm_layer(dim)
+        self.norm2_t = norm_layer(dim)
+        hidden = int(dim * mlp_ratio)
+        self.mlp_s = MLP(in_features=dim, hidden_features=hidden, out_features=dim, act_layer=act_layer, drop=drop)
+        self.mlp_t = MLP(in_features=dim, hidden_features=hidden, out_features=dim, act_layer=act_layer, drop=drop)
+        self.att_fuse = att_fuse
+
+
+class _DSTformerFn(torch.autograd.Function):
+    """One autograd node for the whole backbone: forward and backward are each a
+    fixed sequence of HIP kernel launches on the current stream."""
+
+    @staticmethod
+    def forward(ctx, ops, cfg, names, tdtype, return_rep, x, *params):
+        need_grad = any(ctx.needs_input_grad[5:])
+        P = dict(zip(names, params))
+        eng = Engine(ops, cfg, P, tdtype)
+        out, saved = eng.forward(x, return_rep, need_grad)
+        if need_grad:
+            ctx.eng, ctx.saved_acts, ctx.names = eng, saved, names
+            ctx.pshapes = [p.shape for p in params]
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        eng, saved, names = ctx.eng, ctx.saved_acts, ctx.names
+        if saved is None:
+            raise RuntimeError('DSTformer backward called twice (activations were released)')
+        dout = dout.contiguous().float()
+        sizes = [int(torch.Size(s).numel()) for s in ctx.pshapes]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dout.device)
+        grads: Dict[str, torch.Tensor] = {}
+        off = 0
+        for n, s, sz in zip(names, ctx.pshapes, sizes):
+            grads[n] = flat[off:off + sz].view(s)
+            off += sz
+        dx = eng.backward(saved, dout, grads, want_dx=ctx.needs_input_grad[5])
+        ctx.saved_acts = None
+        ctx.eng = None
+        gp = tuple(grads[n] if ng else None for n, ng in zip(names, ctx.needs_input_grad[6:]))
+        return (None, None, None, None, None, dx) + gp
+
+
+def make_cfg(model) -> ModelCfg:
+    return ModelCfg(dim_in=model.dim_in, dim_out=model.dim_out, C=model.dim_feat, R=model.dim_rep, depth=model.depth,
+                    H=model.num_heads, hidden=int(model.dim_feat * model.mlp_ratio), J=model.num_joints,
+                    maxlen=model.maxlen, eps=model.ln_eps, scale=model.qk_scale or (model.dim_feat // model.num_heads) ** -0.5,
+                    att_fuse=model.att_fuse, qkv_bias=model.qkv_bias)
+
+
+def run(ops, model, x, return_rep=False):
+    """Run the fused path of `model` on `x` with an explicit kernel provider."""
+    cfg = make_cfg(model)
+    names, params = zip(*model.named_parameters())
+    return _DSTformerFn.apply(ops, cfg, names, _DTYPES[model.precision], return_rep, x, *params)
+
+
+class DSTformer(nn.Module):
+    def __init__(self, dim_in=3, dim_out=3, dim_feat=256, dim_rep=512,
+                 depth=5, num_heads=8, mlp_ratio=4,
+                 num_joints=17, maxlen=243,
+                 qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
+                 norm_layer=nn.LayerNorm, att_fuse=True):
+        super().__init__()
+        self.dim_in, self.dim_out, self.dim_feat, self.dim_rep = dim_in, dim_out, dim_feat, dim_rep
+        self.depth, self.num_heads, self.mlp_ratio = depth, num_heads, mlp_ratio
+        self.num_joints, self.maxlen = num_joints, maxlen
+        self.qkv_bias, self.qk_scale = qkv_bias, qk_scale
+        self.drop_rates = (float(drop_rate), float(attn_drop_rate), float(drop_path_rate))
+        #: arithmetic of the GEMM/attention operands: 'bf16' (MFMA bf16, fp32 accumulate, fp32 residual
+        #: stream and statistics) or 'fp32' (exact fp32 MFMA; the 1e-3 parity mode)
+        self.precision = os.environ.get('MBX_PRECISION', 'bf16')
+        self.joints_embed = nn.Linear(dim_in, dim_feat)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
+        mk = lambda i, mode: Block(dim=dim_feat, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                   qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i],
+                                   norm_layer=norm_layer, st_mode=mode)
+        self.blocks_st = nn.ModuleList([mk(i, 'stage_st') for i in range(depth)])
+        self.blocks_ts = nn.ModuleList([mk(i, 'stage_ts') for i in range(depth)])
+        self.norm = norm_layer(dim_feat)
+        if not isinstance(self.norm, nn.LayerNorm) or not self.norm.elementwise_affine:
+            raise NotImplementedError('norm_layer must build an affine nn.LayerNorm (learning.py:84 passes partial(nn.LayerNorm, eps=1e-6))')
+        self.ln_eps = float(self.norm.eps)
+        if dim_rep:
+            self.pre_logits = nn.Sequential(OrderedDict([('fc', nn.Linear(dim_feat, dim_rep)), ('act', nn.Tanh())]))
+        else:
+            self.pre_logits = nn.Identity()
+        self.head = nn.Linear(dim_rep, dim_out) if dim_out > 0 else nn.Identity()
+        self.temp_embed = nn.Parameter(torch.zeros(1, maxlen, 1, dim_feat))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_joints, dim_feat))
+        _trunc_normal_(self.temp_embed, std=.02)
+        _trunc_normal_(self.pos_embed, std=.02)
+        self.apply(self._init_weights)
+        self.att_fuse = att_fuse
+        if self.att_fuse:
+            # built after apply(): starts as an even blend (weight 0, bias 0.5), DSTformer.py:307-311
+            self.ts_attn = nn.ModuleList([nn.Linear(dim_feat * 2, 2) for _ in range(depth)])
+            for lin in self.ts_attn:
+                lin.weight.data.fill_(0)
+                lin.bias.data.fill_(0.5)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, dim_out, global_pool=''):
+        self.dim_out = dim_out
+        self.head = nn.Linear(self.dim_feat, dim_out) if dim_out > 0 else nn.Identity()
+
+    # ------------------------------------------------------------------ checks
+    def _check(self, x):
+        if x.dim() != 4 or x.shape[2] != self.num_joints or x.shape[3] != self.dim_in:
+            raise ValueError(f'expected input [B, T, {self.num_joints}, {self.dim_in}], got {tuple(x.shape)}')
+        if not 1 <= x.shape[1] <= self.maxlen:
+            raise ValueError(f'sequence length {x.shape[1]} outside [1, maxlen={self.maxlen}]')
+        if not x.is_cuda:
+            raise RuntimeError('motionbert_amd.DSTformer has no CPU path: move the model and input to a ROCm device '
+                               '(the arithmetic lives in libmbx.so, gfx950 HIP kernels)')
+        if self.training and any(r > 0 for r in self.drop_rates):
+            raise NotImplementedError('dropout / drop-path > 0 in training is outside the HIP hot path '
+                                      '(every shipped config leaves them at 0: lib/utils/learning.py:83-85)')
+        if not self.dim_rep or self.dim_out <= 0:
+            raise NotImplementedError('dim_rep=0 / dim_out<=0 variants are not used by any shipped config')
+        if self.precision not in _DTYPES:
+            raise ValueError(f"precision must be one of {list(_DTYPES)}, got {self.precision!r}")
+        if isinstance(self.head, nn.Linear) and self.head.in_features != self.dim_rep:
+            raise NotImplementedError('reset_classifier() head with in_features != dim_rep cannot follow pre_logits')
+
+    def forward(self, x, return_rep=False):
+        self._check(x)
+        from . import hip_ops
+        x = x.contiguous().float()
+        return run(hip_ops.get(), self, x, return_rep)
+
+    def get_representation(self, x):
+        return self.forward(x, return_rep=True)
