@@ -1,0 +1,236 @@
+"""bench.py -- clips/sec of the DSTformer hot path (fwd + bwd + AdamW) on N MI355X of one node.
+
+    python bench.py                               # N=1, defaults finish in a couple of minutes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic clips resident in HBM:
+forward + backward of the full MotionBERT backbone (configs/pretrain/MB_pretrain.yaml:18-24 ==
+configs/pose3d/MB_train_h36m.yaml: dim_feat 512, depth 5, 8 heads, mlp_ratio 2, T=243, J=17) at
+64 clips per GPU (MB_pretrain.yaml:10), a pose loss, and the AdamW update -- nothing is skipped
+inside the timed region.  One process per GPU; gradients are all-reduced over RCCL (weak scaling:
+the per-GPU batch is fixed).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      dominant kernel (the bf16 MFMA GEMM gemm_nt): algorithmic FLOPs per launch /
+                average launch duration measured here with HIP events on the launch stream during one
+                extra, untimed, instrumented step; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md)
+  cpu_baseline  the torch fp32 port of the same path (oracle/torch_ops.py) timed on the host cores of
+                this node on a bounded sample (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from functools import partial
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.nn as nn
+
+FULL = dict(dim_in=3, dim_out=3, dim_feat=512, dim_rep=512, depth=5, num_heads=8, mlp_ratio=2, num_joints=17, maxlen=243)
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md chip table
+PEAK_F32_TFLOPS = 157.3
+
+
+def model_flops_fwd(cfg, T):
+    """Matmul FLOPs of one clip forward (closed form of SURVEY.md 8d / BASELINE.md section 2)."""
+    C, R, J, H = cfg['dim_feat'], cfg['dim_rep'], cfg['num_joints'], cfg['num_heads']
+    hid = int(C * cfg['mlp_ratio'])
+    N = T * J
+    lin = 2 * N * C * (3 * C + C + 2 * hid)
+    sp, tm = 4 * T * J * J * C, 4 * J * T * T * C
+    return cfg['depth'] * (2 * (2 * lin + sp + tm)) + cfg['depth'] * 2 * N * 2 * C * 2 + 2 * N * 3 * C + 2 * N * C * R + 2 * N * R * 3
+
+
+def make_batch(B, T, J, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.cat([torch.rand(B, T, J, 2, generator=g) * 2 - 1, torch.rand(B, T, J, 1, generator=g)], -1)
+    gt = torch.randn(B, T, J, 3, generator=g) * 0.3
+    gt = gt - gt[:, :, 0:1]
+    return x.to(device), gt.to(device)
+
+
+def pose_loss(pred, gt):
+    """loss_mpjpe + 20 * loss_velocity, restated (lib/model/loss.py:56-66,133-142; MB_train_h36m.yaml:38-39)."""
+    mpjpe = torch.mean(torch.norm(pred - gt, dim=-1))
+    vel = torch.mean(torch.norm((pred[:, 1:] - pred[:, :-1]) - (gt[:, 1:] - gt[:, :-1]), dim=-1)) if pred.shape[1] > 1 else 0.0
+    return mpjpe + 20.0 * vel
+
+
+class TimedOps:
+    """Wraps the kernel provider for ONE instrumented step: HIP events around every C-ABI call."""
+
+    def __init__(self, ops):
+        self._ops, self.rec = ops, []
+
+    def __getattr__(self, name):
+        fn = getattr(self._ops, name)
+        if not callable(fn) or name.startswith('_'):
+            return fn
+
+        def wrapped(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            flops = 0.0
+            if name == 'gemm_nt':
+                flops = 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]
+            elif name == 'gemm_tn':
+                flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
+            self.rec.append((name, flops, e0, e1))
+            return r
+        return wrapped
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, e0, e1 in self.rec:
+            d = agg.setdefault(name, dict(calls=0, ms=0.0, flops=0.0))
+            d['calls'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += flops
+        return agg
+
+
+def cpu_baseline(cfg, T, budget_s=20.0):
+    """Torch fp32 port of the hot path on the host cores (oracle/torch_ops.py), fwd+bwd, small batch."""
+    from motionbert_amd import DSTformer, model as M
+    from oracle.torch_ops import MockOps
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = DSTformer(norm_layer=partial(nn.LayerNorm, eps=1e-6), **cfg)
+    m.precision = 'fp32'
+    B = 2
+    x, gt = make_batch(B, T, cfg['num_joints'], 1, 'cpu')
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        loss = pose_loss(M.run(MockOps(), m, x), gt)
+        loss.backward()
+    t0 = time.time(); step(); first = time.time() - t0   # warm-up (also sizes the sample)
+    iters = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(iters):
+        step()
+    dt = (time.time() - t0) / iters
+    cpu = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
+    except Exception:
+        pass
+    return dict(value=B / dt, unit='clips/s', cores=cores, kind='port',
+                sample=f'torch fp32 port (oracle/torch_ops.py) of the full model fwd+bwd, B={B} T={T}, {iters} timed iter(s) after 1 warm-up, {cores} threads, CPU: {cpu}')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
+    ap.add_argument('--frames', type=int, default=243)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a ROCm device (the hot path has no CPU implementation)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)   # RCCL over xGMI
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+
+    from motionbert_amd import DSTformer, hip_ops, model as M
+    torch.manual_seed(0)
+    model = DSTformer(norm_layer=partial(nn.LayerNorm, eps=1e-6), **FULL).to(dev)
+    model.precision = args.precision
+    net = model
+    if world > 1:
+        net = nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.01, fused=True)
+    B, T, J = args.batch, args.frames, FULL['num_joints']
+    x, gt = make_batch(B, T, J, 100 + rank, dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = pose_loss(net(x), gt)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    clips = B * world * args.steps / dt
+
+    # ---- one extra instrumented step (untimed): per-kernel HIP-event durations -> roofline of the dominant kernel
+    roof, breakdown = None, None
+    if rank == 0:
+        timed = TimedOps(hip_ops.get())
+        opt.zero_grad(set_to_none=True)
+        loss = pose_loss(M.run(timed, model, x), gt)
+        loss.backward()
+        agg = timed.summary()
+        tot = sum(d['ms'] for d in agg.values())
+        breakdown = {k: dict(calls=d['calls'], ms=round(d['ms'], 3), share=round(d['ms'] / tot, 4)) for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
+        dom = max(agg, key=lambda k: agg[k]['ms'])
+        d = agg['gemm_nt']
+        peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+        ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel='gemm_nt_kernel', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                    traffic=None, launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
+                    flops_per_launch=d['flops'] / d['calls'], dominant_by_time=dom)
+    flops_step = 3.0 * model_flops_fwd(FULL, T) * B
+    out = {
+        'metric': 'clips/sec [B,243,17,3] DSTformer fwd+bwd', 'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': f'MotionBERT full DSTformer (dim_feat 512, depth 5, 8 heads, mlp_ratio 2) train step: fwd + bwd + AdamW, '
+                               f'{B} clips/GPU x T={T} x J={J}, random-init weights, pose loss (mpjpe + 20 velocity)',
+                   'global_batch': B * world, 'frames': T, 'parallelism': f'dp{world}'},
+        'model_tflops': round(flops_step * world / (ms * 1e-3) / 1e12, 1),
+        'model_mfma_frac': round(flops_step / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS), 4),
+        'roofline': roof, 'kernel_breakdown_ms': breakdown,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(FULL, T)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

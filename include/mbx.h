@@ -1,0 +1,120 @@
+/* mbx.h -- C ABI of libmbx.so: the MI355X (gfx950) kernel set behind the DSTformer hot path.
+ *
+ * The reference (Walter0807/MotionBERT) has no FFI: its hot path is the Python class
+ * lib/model/DSTformer.py:269-361 running on stock ATen ops.  This header is therefore the
+ * boundary this project defines for that path; each entry names the reference arithmetic it
+ * replaces (file:line in the reference checkout).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is DEVICE memory owned by the caller (PyTorch);
+ *     the library never allocates, frees, caches or synchronises;
+ *   - every call enqueues kernels on `stream` (a hipStream_t passed as void*) and returns;
+ *   - return 0 on success, non-zero on argument/launch error; mbx_last_error() gives the
+ *     text (thread-local).  No C++ exceptions cross the ABI;
+ *   - re-entrant, no mutable global state (DataParallel replica threads, autograd thread);
+ *   - `dtype` selects the operand type T of GEMM/attention tensors:
+ *       MBX_BF16  bf16 operands, fp32 MFMA accumulation      (v_mfma_f32_32x32x16_bf16)
+ *       MBX_F32   fp32 operands, exact fp32 MFMA              (v_mfma_f32_32x32x2_f32)
+ *     residual stream, statistics and parameter gradients are always fp32;
+ *   - token index m = (b*T + t)*J + j; tensors are dense row-major.
+ */
+#ifndef MBX_H
+#define MBX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum mbx_dtype { MBX_F32 = 0, MBX_BF16 = 1 };
+
+/* GEMM epilogues (fused into the store of the accumulator tile) */
+enum mbx_epilogue {
+    MBX_EPI_STORE = 0, /* out_t = acc + bias                          qkv (DSTformer.py:103,143) / dX GEMMs */
+    MBX_EPI_GELU  = 1, /* out_t = acc + bias; out2_t = gelu_erf(.)    fc1 + nn.GELU (DSTformer.py:80-81)   */
+    MBX_EPI_RESID = 2, /* out_f = resid + acc + bias                  proj / fc2 + residual (:241-249)     */
+    MBX_EPI_TANH  = 3, /* out_f = tanh(acc + bias)                    pre_logits fc + Tanh (:294-297,354)  */
+    MBX_EPI_DGELU = 4  /* out_t = acc * gelu_erf'(aux_t)              backward of nn.GELU                  */
+};
+
+enum mbx_attn_mode {
+    MBX_ATTN_SPATIAL  = 0, /* softmax over the J joints of one frame   (DSTformer.py:178-186) */
+    MBX_ATTN_TEMPORAL = 1  /* softmax over the T frames of one joint   (DSTformer.py:188-200) */
+};
+
+const char* mbx_last_error(void);
+int mbx_version(void);
+
+/* ---- weights ------------------------------------------------------------------------------
+ * One launch converts every nn.Linear weight of the model: for descriptor i, src fp32 [N,K] ->
+ * dst_n T [N,K] (may be NULL) and dst_t T [K,N] (transposed copy for the dX GEMMs, may be NULL).
+ * `desc` is a device array of n_desc records {src, dst_n, dst_t, N, K} (5 x int64). */
+int mbx_prep_weights(const int64_t* desc, int n_desc, int max_n, int max_k, int dtype, void* stream);
+
+/* ---- embedding: joints_embed + pos_embed + temp_embed (DSTformer.py:330-337) --------------
+ * x [B,T,J,Din] f32, w [C,Din], b [C], pos [J,C], temp [>=T,C]  ->  h [M,C] f32 */
+int mbx_embed_fwd(const float* x, const float* w, const float* b, const float* pos, const float* temp,
+                  float* h, int B, int T, int J, int Din, int C, void* stream);
+/* dh [M,C] -> dw [C,Din], db [C], dpos [J,C], dtemp [T,C] (rows >= T untouched), dx [M,Din] or NULL.
+ * ws: >= mbx_embed_bwd_ws(T,J,Din,C) bytes. */
+size_t mbx_embed_bwd_ws(int T, int J, int Din, int C);
+int mbx_embed_bwd(const float* dh, const float* x, const float* w, float* dw, float* db, float* dpos,
+                  float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm, biased variance, eps inside sqrt; DSTformer.py:221-222,230-231,292)
+ * x [M,C] f32 -> y [M,C] T, mean [M], rstd [M] */
+int mbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* y,
+                      float* mean, float* rstd, int M, int C, int dtype, void* stream);
+/* dx = LN'(dy) [+ dres] [+ extra]  (f32);  dx_t = T copy of dx (or NULL);  dgamma, dbeta [C].
+ * ws: >= mbx_layernorm_bwd_ws(C) bytes. */
+size_t mbx_layernorm_bwd_ws(int C);
+int mbx_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* dres, const float* extra, float* dx, void* dx_t, float* dgamma, float* dbeta,
+                      int M, int C, int dtype, void* ws, void* stream);
+
+/* ---- GEMMs on MFMA -------------------------------------------------------------------------
+ * acc[M,N] = a[M,K] . w[N,K]^T  (nn.Linear, DSTformer.py:74,76,97,103,295), epilogue per mbx_epilogue.
+ * K % 64 == 0 (bf16) / K % 32 == 0 (f32), N % 8 == 0. Unused pointers NULL. */
+int mbx_gemm_nt(const void* a, const void* w, const float* bias, int epilogue, void* out_t, void* out2_t,
+                float* out_f, const float* resid, const void* aux_t, int M, int N, int K, int dtype, void* stream);
+/* dw[N,K] = dy[M,N]^T . a[M,K] (f32);  db[N] = column sums of dy (or NULL).  N % 32 == 0, K % 32 == 0.
+ * ws: >= mbx_gemm_tn_ws(M,N,K) bytes. */
+size_t mbx_gemm_tn_ws(int M, int N, int K);
+int mbx_gemm_tn(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, int dtype,
+                void* ws, void* stream);
+
+/* ---- attention core (DSTformer.py:178-200), qkv [M,3C] T with channel order [3][H][hd] --------
+ * o [M,C] T (heads concatenated), lse [M,H] f32 = log-sum-exp of the scaled scores.
+ * hd = C/H must be 32 or 64; J <= 32; T <= 256. */
+int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale,
+                 int mode, int dtype, void* stream);
+/* dqkv [M,3C] T from do [M,C] T; probabilities are recomputed from q, k and lse. */
+int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T,
+                 int J, int H, int hd, float scale, int mode, int dtype, void* stream);
+
+/* ---- adaptive fusion of the two streams (DSTformer.py:343-349) -------------------------------
+ * alpha = softmax(w . cat[x_st, x_ts] + b)  [M,2];  out = x_st*alpha0 + x_ts*alpha1.  w [2,2C], b [2]. */
+int mbx_fuse_fwd(const float* x_st, const float* x_ts, const float* w, const float* b, float* out, float* alpha,
+                 int M, int C, void* stream);
+size_t mbx_fuse_bwd_ws(int C);
+int mbx_fuse_bwd(const float* dh, const float* x_st, const float* x_ts, const float* alpha, const float* w,
+                 float* d_st, float* d_ts, void* d_st_t, void* d_ts_t, float* dw, float* db, int M, int C,
+                 int dtype, void* ws, void* stream);
+/* att_fuse=False variant (DSTformer.py:351): out = (x_st + x_ts)/2 and its backward */
+int mbx_average(const float* x_st, const float* x_ts, float* out, size_t n, void* stream);
+int mbx_average_bwd(const float* dh, float* d_st, float* d_ts, void* d_st_t, void* d_ts_t, size_t n, int dtype,
+                    void* stream);
+
+/* ---- tail: head Linear(R -> Dout<=8) (DSTformer.py:300,357) and tanh' ---------------------------- */
+int mbx_head_fwd(const float* rep, const float* w, const float* b, float* out, int M, int R, int Dout, void* stream);
+size_t mbx_head_bwd_ws(int R, int Dout);
+/* dpre_t = (dout . w) * (1 - rep^2) (T);  dw [Dout,R];  db [Dout] */
+int mbx_head_bwd(const float* dout, const float* rep, const float* w, void* dpre_t, float* dw, float* db,
+                 int M, int R, int Dout, int dtype, void* ws, void* stream);
+int mbx_tanh_bwd(const float* drep, const float* rep, void* dpre_t, size_t n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBX_H */

@@ -1,0 +1,548 @@
+// Spatial (17 joints) and temporal (<= 243 frames) multi-head attention of the DSTformer for gfx950
+// (reference: lib/model/DSTformer.py:178-186 forward_spatial, :188-200 forward_temporal).
+//
+// One "problem" is one (frame, head) [spatial, L = J keys] or one (clip, joint, head) [temporal,
+// L = T keys].  Sequence element s of a problem is token tok0 + s*tstep of the packed qkv tensor
+// [M, 3C] (channel order [3][H][hd]); the temporal problems therefore read their rows with a stride
+// of J*3C elements straight from the [B,T,J,3C] layout -- no permute/contiguous copies.
+//
+// Everything is MFMA 32x32 (bf16: 32x32x16, fp32: 32x32x2) in the "transposed" orientation: the
+// query (or, in the dK/dV kernel, the key) index is the LANE, so each lane owns whole softmax rows:
+//     S^T[key][q]  = sum_d K[key][d]  Q[q][d]      A operand: K rows from LDS,  B operand: Q from registers
+//     O^T[d][q]    = sum_k V^T[d][k]  P^T[k][q]    A operand: V^T rows from LDS, B operand: P, already in
+//                                                  registers in exactly the layout the MFMA wants
+// so the softmax needs no LDS and only ONE cross-lane exchange (lanes l and l+32 share a query):
+// row max and row sum are in-register reductions followed by a single __shfl_xor(.., 32).
+// The score matrix [B,H,J,T,T] that the reference materialises (32 MB per clip) never exists;
+// backward recomputes the probabilities from q, k and the saved log-sum-exp.
+//
+// LDS tiles (per problem):  row-major [KP][hd] tiles padded by 16 B per row (conflict-free 16-byte
+// fragment reads), and for bf16 additionally transposed tiles [hd][KP] (+16 B) built with 8x8
+// register transposes, because an MFMA operand needs its contraction index contiguous per lane.
+// In fp32 mode operands are single floats per lane, so "transposed" reads come straight out of the
+// row-major tile.
+// Short sequences (L <= 32: every spatial problem, temporal with T <= 32) run one problem per wave
+// with wave-private LDS, four problems per 256-thread workgroup; longer ones share K/V across the 4
+// waves of a workgroup, which split the 32-row query (key) blocks between them.
+#include "mbx_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// per-type helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct AT;
+template <> struct AT<bf16_t> { static constexpr int EPC = 8, RB = 8, SZ = 2; };
+template <> struct AT<float>  { static constexpr int EPC = 4, RB = 4, SZ = 4; };
+
+// B operand of the "rows" products: the d-vector of ONE sequence element, held by the two lanes
+// (g = 0, 1) that own it.   bf16: v[s] = 8 bf16 at d = 16 s + 8 g;   fp32: v[c] = 2 floats at d = 4 c + 2 g
+template <typename T, int HD> struct BReg;
+template <int HD> struct BReg<bf16_t, HD> {
+    uint4 v[HD / 16];
+    __device__ __forceinline__ void load(const bf16_t* row, int g, bool valid) {
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s)
+            v[s] = valid ? *reinterpret_cast<const uint4*>(row + 16 * s + 8 * g) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    // sum_d a[d]*b[d] over this lane's half of the d range
+    static __device__ __forceinline__ float dot(const BReg& a, const BReg& b) {
+        float acc = 0.f;
+        const uint32_t* x = reinterpret_cast<const uint32_t*>(a.v);
+        const uint32_t* y = reinterpret_cast<const uint32_t*>(b.v);
+#pragma unroll
+        for (int i = 0; i < HD / 4; ++i) {
+            acc = fmaf(__uint_as_float(x[i] << 16), __uint_as_float(y[i] << 16), acc);
+            acc = fmaf(__uint_as_float(x[i] & 0xffff0000u), __uint_as_float(y[i] & 0xffff0000u), acc);
+        }
+        return acc;
+    }
+};
+template <int HD> struct BReg<float, HD> {
+    float2 v[HD / 4];
+    __device__ __forceinline__ void load(const float* row, int g, bool valid) {
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c)
+            v[c] = valid ? *reinterpret_cast<const float2*>(row + 4 * c + 2 * g) : make_float2(0.f, 0.f);
+    }
+    static __device__ __forceinline__ float dot(const BReg& a, const BReg& b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) acc = fmaf(a.v[c].x, b.v[c].x, fmaf(a.v[c].y, b.v[c].y, acc));
+        return acc;
+    }
+};
+
+// acc[i][lane] += sum_d tile[row0 + i][d] * B[lane][d]     (tile row-major in LDS, `stride` bytes per row)
+template <typename T, int HD> struct MmaRows;
+template <int HD> struct MmaRows<bf16_t, HD> {
+    static __device__ __forceinline__ void run(const char* tile, int stride, int row0, const BReg<bf16_t, HD>& b, int lane,
+                                               f32x16_t& acc) {
+        const char* p = tile + (size_t)(row0 + (lane & 31)) * stride + (lane >> 5) * 16;
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(p + s * 32);
+            const bf16x8_t bb = *reinterpret_cast<const bf16x8_t*>(&b.v[s]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc, 0, 0, 0);
+        }
+    }
+};
+template <int HD> struct MmaRows<float, HD> {
+    static __device__ __forceinline__ void run(const char* tile, int stride, int row0, const BReg<float, HD>& b, int lane,
+                                               f32x16_t& acc) {
+        const char* p = tile + (size_t)(row0 + (lane & 31)) * stride + (lane >> 5) * 8;
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) {
+            const float2 a = *reinterpret_cast<const float2*>(p + c * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.v[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.v[c].y, acc, 0, 0, 0);
+        }
+    }
+};
+
+// acc[i][lane] += sum_{e in fragment f} X[e][d0 + i] * P[e][lane]
+// P is a 32x32 accumulator fragment (16 registers): register r of lane (., g) belongs to sequence
+// element  e(f, r, g) = 32 f + (r & 3) + 8 (r >> 2) + 4 g.
+//   bf16: `tile` is the TRANSPOSED tile [d][e] (e contiguous): two 8-byte reads give the 8 elements of a k-step
+//   fp32: `tile` is the ROW-MAJOR tile [e][d]: scalar reads, consecutive lanes -> consecutive d
+template <typename T> struct MmaCols;
+template <> struct MmaCols<bf16_t> {
+    static __device__ __forceinline__ void run(const char* tile, int stride, int d0, int f, const f32x16_t& p, int lane,
+                                               f32x16_t& acc) {
+        const int g = lane >> 5;
+        const char* row = tile + (size_t)(d0 + (lane & 31)) * stride + (32 * f + 4 * g) * 2;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            union { uint32_t u[4]; bf16x8_t v; } pb, a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pb.u[e] = pack_bf2(p[8 * t + 2 * e], p[8 * t + 2 * e + 1]);
+            const uint2 lo = *reinterpret_cast<const uint2*>(row + 32 * t);
+            const uint2 hi = *reinterpret_cast<const uint2*>(row + 32 * t + 16);
+            a.u[0] = lo.x; a.u[1] = lo.y; a.u[2] = hi.x; a.u[3] = hi.y;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, pb.v, acc, 0, 0, 0);
+        }
+    }
+};
+template <> struct MmaCols<float> {
+    static __device__ __forceinline__ void run(const char* tile, int stride, int d0, int f, const f32x16_t& p, int lane,
+                                               f32x16_t& acc) {
+        const int g = lane >> 5;
+        const char* col = tile + (size_t)(d0 + (lane & 31)) * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const float a = *reinterpret_cast<const float*>(col + (size_t)e * stride);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p[r], acc, 0, 0, 0);
+        }
+    }
+};
+
+// ---- LDS tile fills (cooperative over `gsize` threads, this thread = gtid) -------------------------
+// row-major: dst[row][0..HD) = src[row * rstride + 0..HD)  for row < L, zero for L <= row < KP
+template <typename T, int HD>
+__device__ __forceinline__ void fill_rowmajor(char* dst, int stride, const T* src, size_t rstride, int L, int KP, int gtid,
+                                              int gsize) {
+    constexpr int CH = HD / AT<T>::EPC;
+    for (int idx = gtid; idx < KP * CH; idx += gsize) {
+        const int row = idx / CH, ch = idx % CH;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < L) v = *reinterpret_cast<const uint4*>(src + (size_t)row * rstride + ch * AT<T>::EPC);
+        *reinterpret_cast<uint4*>(dst + (size_t)row * stride + ch * 16) = v;
+    }
+}
+// transposed (bf16 only): dst[d][row] = src[row][d]
+template <int HD>
+__device__ __forceinline__ void fill_transposed(char* dst, int stride, const bf16_t* src, size_t rstride, int L, int KP,
+                                                int gtid, int gsize) {
+    const int nkb = KP / 8;
+    for (int blk = gtid; blk < nkb * (HD / 8); blk += gsize) {
+        const int kb = blk % nkb, db = blk / nkb;
+        uint32_t rw[32];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (kb * 8 + i < L) v = *reinterpret_cast<const uint4*>(src + (size_t)(kb * 8 + i) * rstride + db * 8);
+            rw[i * 4] = v.x; rw[i * 4 + 1] = v.y; rw[i * 4 + 2] = v.z; rw[i * 4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t ow[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t lo = rw[(2 * d) * 4 + (c >> 1)], hi = rw[(2 * d + 1) * 4 + (c >> 1)];
+                ow[d] = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            }
+            *reinterpret_cast<uint4*>(dst + (size_t)(db * 8 + c) * stride + kb * 16) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+}
+
+// store an accumulator pair/quad set: lane owns sequence element `row`, registers own d
+template <typename T, int HD>
+__device__ __forceinline__ void store_rowfrag(T* row, const f32x16_t (&acc)[HD / 32], float mul, int g) {
+#pragma unroll
+    for (int df = 0; df < HD / 32; ++df)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v[4] = {acc[df][4 * q] * mul, acc[df][4 * q + 1] * mul, acc[df][4 * q + 2] * mul, acc[df][4 * q + 3] * mul};
+            store4<T>(row + df * 32 + 8 * q + 4 * g, v);
+        }
+}
+
+struct Prob {
+    size_t tok0;
+    int tstep, L, h;
+};
+__device__ __forceinline__ Prob decode_prob(int prob, int mode, int Tn, int J, int H) {
+    Prob p;
+    p.h = prob % H;
+    const int rest = prob / H;
+    if (mode == MBX_ATTN_SPATIAL) {
+        p.tok0 = (size_t)rest * J; p.tstep = 1; p.L = J;
+    } else {
+        const int j = rest % J, b = rest / J;
+        p.tok0 = (size_t)b * Tn * J + j; p.tstep = J; p.L = Tn;
+    }
+    return p;
+}
+
+template <typename T> __host__ __device__ constexpr int rm_stride(int HD) { return HD * AT<T>::SZ + 16; }   // row-major tile
+__host__ __device__ constexpr int tr_stride(int KP) { return KP * 2 + 16; }                                  // transposed (bf16)
+
+// ================================================================================================
+// forward: flash-style walk over 32-key fragments with a running row max / row sum (the whole row
+// is at most 8 fragments, but keeping only one fragment of scores live keeps the wave at ~100 VGPRs)
+// ================================================================================================
+template <typename T, int HD, bool SHARED>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+                                                       int Tn, int J, int H, float scale, int mode, int nprob, int KP) {
+    constexpr bool IS_BF = sizeof(T) == 2;
+    constexpr int KSTR = rm_stride<T>(HD);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+    const int C = H * HD, C3 = 3 * C;
+    const int VSTR = IS_BF ? tr_stride(KP) : KSTR;
+    const int KBYTES = KP * KSTR;
+    const int VBYTES = IS_BF ? HD * VSTR : KP * VSTR;
+    int prob = SHARED ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const bool pvalid = prob < nprob;
+    prob = min(prob, nprob - 1);
+    const Prob P = decode_prob(prob, mode, Tn, J, H);
+    const int gtid = SHARED ? tid : lane, gsize = SHARED ? 256 : 64;
+    char* kt = smem + (SHARED ? 0 : wave * (KBYTES + VBYTES));
+    char* vt = kt + KBYTES;
+    const size_t rstride = (size_t)P.tstep * C3;
+    const T* base = qkv + P.tok0 * C3 + (size_t)P.h * HD;
+    fill_rowmajor<T, HD>(kt, KSTR, base + C, rstride, P.L, KP, gtid, gsize);
+    if constexpr (IS_BF)
+        fill_transposed<HD>(vt, VSTR, reinterpret_cast<const bf16_t*>(base + 2 * C), rstride, P.L, KP, gtid, gsize);
+    else
+        fill_rowmajor<T, HD>(vt, VSTR, base + 2 * C, rstride, P.L, KP, gtid, gsize);
+    __syncthreads();
+
+    const int nfr = (P.L + 31) / 32;
+    for (int qb = SHARED ? wave : 0; qb < nfr; qb += SHARED ? 4 : 1) {
+        const int q = qb * 32 + (lane & 31);
+        const bool qvalid = pvalid && q < P.L;
+        const size_t tok = P.tok0 + (size_t)min(q, P.L - 1) * P.tstep;
+        BReg<T, HD> qreg;
+        qreg.load(qkv + tok * C3 + (size_t)P.h * HD, g, qvalid);
+        f32x16_t oacc[HD / 32];
+#pragma unroll
+        for (int df = 0; df < HD / 32; ++df)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[df][r] = 0.f;
+        float m = -INFINITY, l = 0.f;  // l: this lane's half of the row sum (lanes l, l^32 share a query)
+        for (int f = 0; f < nfr; ++f) {
+            f32x16_t s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            MmaRows<T, HD>::run(kt, KSTR, 32 * f, qreg, lane, s);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+                s[r] = key < P.L ? s[r] * scale : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // every fragment f < nfr holds >= 1 valid key: finite
+            const float mn = fmaxf(m, mx);
+            const float corr = __expf(m - mn);        // first fragment: exp(-inf) = 0
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __expf(s[r] - mn);
+                ps += s[r];
+            }
+            l = fmaf(l, corr, ps);
+            m = mn;
+#pragma unroll
+            for (int df = 0; df < HD / 32; ++df) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[df][r] *= corr;
+                MmaCols<T>::run(vt, VSTR, df * 32, f, s, lane, oacc[df]);
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        if (qvalid) {
+            store_rowfrag<T, HD>(o + tok * C + (size_t)P.h * HD, oacc, 1.0f / l, g);
+            if (g == 0) lse[tok * H + P.h] = m + __logf(l);
+        }
+    }
+}
+
+// ================================================================================================
+// backward, part 1: dQ   (lane = query)
+// ================================================================================================
+template <typename T, int HD, bool SHARED>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                          const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                          T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
+                                                          int nprob, int KP) {
+    constexpr bool IS_BF = sizeof(T) == 2;
+    constexpr int RSTR = rm_stride<T>(HD);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+    const int C = H * HD, C3 = 3 * C;
+    const int TSTR = tr_stride(KP);
+    const int per_prob = 2 * KP * RSTR + (IS_BF ? HD * TSTR : 0);
+    int prob = SHARED ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const bool pvalid = prob < nprob;
+    prob = min(prob, nprob - 1);
+    const Prob P = decode_prob(prob, mode, Tn, J, H);
+    const int gtid = SHARED ? tid : lane, gsize = SHARED ? 256 : 64;
+    char* kt = smem + (SHARED ? 0 : wave * per_prob);
+    char* vt = kt + KP * RSTR;
+    char* ktt = vt + KP * RSTR;  // bf16 only: K^T
+    const size_t rstride = (size_t)P.tstep * C3;
+    const T* base = qkv + P.tok0 * C3 + (size_t)P.h * HD;
+    fill_rowmajor<T, HD>(kt, RSTR, base + C, rstride, P.L, KP, gtid, gsize);
+    fill_rowmajor<T, HD>(vt, RSTR, base + 2 * C, rstride, P.L, KP, gtid, gsize);
+    if constexpr (IS_BF) fill_transposed<HD>(ktt, TSTR, reinterpret_cast<const bf16_t*>(base + C), rstride, P.L, KP, gtid, gsize);
+    __syncthreads();
+
+    const int nfr = (P.L + 31) / 32;
+    for (int qb = SHARED ? wave : 0; qb < nfr; qb += SHARED ? 4 : 1) {
+        const int q = qb * 32 + (lane & 31);
+        const bool qvalid = pvalid && q < P.L;
+        const size_t tok = P.tok0 + (size_t)min(q, P.L - 1) * P.tstep;
+        BReg<T, HD> qreg, doreg, oreg;
+        qreg.load(qkv + tok * C3 + (size_t)P.h * HD, g, qvalid);
+        doreg.load(d_o + tok * C + (size_t)P.h * HD, g, qvalid);
+        oreg.load(o + tok * C + (size_t)P.h * HD, g, qvalid);
+        float delta = BReg<T, HD>::dot(doreg, oreg);
+        delta += __shfl_xor(delta, 32, 64);
+        const float lq = qvalid ? lse[tok * H + P.h] : 0.f;
+
+        f32x16_t dq[HD / 32];
+#pragma unroll
+        for (int df = 0; df < HD / 32; ++df)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[df][r] = 0.f;
+        for (int f = 0; f < nfr; ++f) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            MmaRows<T, HD>::run(kt, RSTR, 32 * f, qreg, lane, s);
+            MmaRows<T, HD>::run(vt, RSTR, 32 * f, doreg, lane, dp);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const float p = (qvalid && key < P.L) ? __expf(s[r] * scale - lq) : 0.f;
+                s[r] = p * (dp[r] - delta) * scale;  // dS
+            }
+#pragma unroll
+            for (int df = 0; df < HD / 32; ++df) MmaCols<T>::run(IS_BF ? ktt : kt, IS_BF ? TSTR : RSTR, df * 32, f, s, lane, dq[df]);
+        }
+        if (qvalid) store_rowfrag<T, HD>(dqkv + tok * C3 + (size_t)P.h * HD, dq, 1.0f, g);
+    }
+}
+
+// ================================================================================================
+// backward, part 2: dK, dV   (lane = key)
+// ================================================================================================
+template <typename T, int HD, bool SHARED>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                           const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                           T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
+                                                           int nprob, int KP) {
+    constexpr bool IS_BF = sizeof(T) == 2;
+    constexpr int RSTR = rm_stride<T>(HD);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+    const int C = H * HD, C3 = 3 * C;
+    const int TSTR = tr_stride(KP);
+    const int per_prob = 2 * KP * RSTR + (IS_BF ? 2 * HD * TSTR : 0) + 2 * KP * 4;
+    int prob = SHARED ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const bool pvalid = prob < nprob;
+    prob = min(prob, nprob - 1);
+    const Prob P = decode_prob(prob, mode, Tn, J, H);
+    const int gtid = SHARED ? tid : lane, gsize = SHARED ? 256 : 64;
+    char* qt = smem + (SHARED ? 0 : wave * per_prob);   // Q   [KP][hd]
+    char* dot_ = qt + KP * RSTR;                          // dO  [KP][hd]
+    char* qtt = dot_ + KP * RSTR;                         // bf16: Q^T  [hd][KP]
+    char* dott = qtt + (IS_BF ? HD * TSTR : 0);           // bf16: dO^T [hd][KP]
+    float* lse_s = reinterpret_cast<float*>(dott + (IS_BF ? HD * TSTR : 0));
+    float* del_s = lse_s + KP;
+    const size_t rstride = (size_t)P.tstep * C3, ostride = (size_t)P.tstep * C;
+    const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
+    const T* dobase = d_o + P.tok0 * C + (size_t)P.h * HD;
+    const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
+    fill_rowmajor<T, HD>(qt, RSTR, qbase, rstride, P.L, KP, gtid, gsize);
+    fill_rowmajor<T, HD>(dot_, RSTR, dobase, ostride, P.L, KP, gtid, gsize);
+    if constexpr (IS_BF) {
+        fill_transposed<HD>(qtt, TSTR, reinterpret_cast<const bf16_t*>(qbase), rstride, P.L, KP, gtid, gsize);
+        fill_transposed<HD>(dott, TSTR, reinterpret_cast<const bf16_t*>(dobase), ostride, P.L, KP, gtid, gsize);
+    }
+    // per-query statistics: lse and delta = sum_d dO*O
+    for (int q = gtid; q < KP; q += gsize) {
+        float l = 0.f, dl = 0.f;
+        if (q < P.L) {
+            l = lse[(P.tok0 + (size_t)q * P.tstep) * H + P.h];
+            const T* a = dobase + (size_t)q * ostride;
+            const T* b = obase + (size_t)q * ostride;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                float x[4], y[4];
+                load4<T>(a + d, x);
+                load4<T>(b + d, y);
+                dl = fmaf(x[0], y[0], fmaf(x[1], y[1], fmaf(x[2], y[2], fmaf(x[3], y[3], dl))));
+            }
+        }
+        lse_s[q] = l;
+        del_s[q] = dl;
+    }
+    __syncthreads();
+
+    const int nfr = (P.L + 31) / 32;
+    for (int kb = SHARED ? wave : 0; kb < nfr; kb += SHARED ? 4 : 1) {
+        const int key = kb * 32 + (lane & 31);
+        const bool kvalid = pvalid && key < P.L;
+        const size_t tok = P.tok0 + (size_t)min(key, P.L - 1) * P.tstep;
+        BReg<T, HD> kreg, vreg;
+        kreg.load(qkv + tok * C3 + C + (size_t)P.h * HD, g, kvalid);
+        vreg.load(qkv + tok * C3 + 2 * C + (size_t)P.h * HD, g, kvalid);
+        f32x16_t dk[HD / 32], dv[HD / 32];
+#pragma unroll
+        for (int df = 0; df < HD / 32; ++df)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[df][r] = 0.f; dv[df][r] = 0.f; }
+        for (int f = 0; f < nfr; ++f) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            MmaRows<T, HD>::run(qt, RSTR, 32 * f, kreg, lane, s);      // s[r]  <-> (query e(f,r,g), key = lane)
+            MmaRows<T, HD>::run(dot_, RSTR, 32 * f, vreg, lane, dp);   // dP
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int q0 = 32 * f + 8 * qd + 4 * g;
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0);
+                const float4 d4 = *reinterpret_cast<const float4*>(del_s + q0);
+                const float la[4] = {l4.x, l4.y, l4.z, l4.w}, da[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * qd + e;
+                    const float p = (kvalid && q0 + e < P.L) ? __expf(s[r] * scale - la[e]) : 0.f;
+                    dp[r] = p * (dp[r] - da[e]) * scale;  // dS
+                    s[r] = p;                              // P
+                }
+            }
+#pragma unroll
+            for (int df = 0; df < HD / 32; ++df) {
+                MmaCols<T>::run(IS_BF ? dott : dot_, IS_BF ? TSTR : RSTR, df * 32, f, s, lane, dv[df]);   // dV^T += dO^T P
+                MmaCols<T>::run(IS_BF ? qtt : qt, IS_BF ? TSTR : RSTR, df * 32, f, dp, lane, dk[df]);     // dK^T += Q^T dS
+            }
+        }
+        if (kvalid) {
+            store_rowfrag<T, HD>(dqkv + tok * C3 + C + (size_t)P.h * HD, dk, 1.0f, g);
+            store_rowfrag<T, HD>(dqkv + tok * C3 + 2 * C + (size_t)P.h * HD, dv, 1.0f, g);
+        }
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int check_attn_args(const char* who, int B, int T, int J, int H, int hd, int mode, int dtype) {
+    MBX_CHECK_ARG(B > 0 && T > 0 && J > 0 && H > 0, "%s: bad shape", who);
+    MBX_CHECK_ARG(hd == 32 || hd == 64, "%s: head dim %d unsupported (32 or 64)", who, hd);
+    MBX_CHECK_ARG(mode == MBX_ATTN_SPATIAL || mode == MBX_ATTN_TEMPORAL, "%s: unknown mode %d", who, mode);
+    MBX_CHECK_ARG(dtype == MBX_BF16 || dtype == MBX_F32, "%s: unknown dtype %d", who, dtype);
+    const int L = mode == MBX_ATTN_SPATIAL ? J : T;
+    MBX_CHECK_ARG(L <= 256, "%s: sequence length %d > 256 unsupported", who, L);
+    return 0;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes, const char* who) {
+    if (bytes > 160 * 1024) return mbx_set_error("%s: needs %zu bytes of LDS (> 160 KiB)", who, bytes);
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return mbx_set_error("%s: hipFuncSetAttribute(%zu): %s", who, bytes, hipGetErrorString(e));
+    }
+    return 0;
+}
+
+template <typename T, int HD, bool SHARED>
+static int launch_fwd(const void* qkv, void* o, float* lse, int Tn, int J, int H, float scale, int mode, int nprob, int KP, hipStream_t s) {
+    constexpr bool IS_BF = sizeof(T) == 2;
+    const size_t per = (size_t)KP * rm_stride<T>(HD) + (IS_BF ? (size_t)HD * tr_stride(KP) : (size_t)KP * rm_stride<T>(HD));
+    const size_t shm = SHARED ? per : 4 * per;
+    auto kern = attn_fwd_kernel<T, HD, SHARED>;
+    if (set_lds(kern, shm, "attn_fwd")) return 1;
+    const int grid = SHARED ? nprob : (nprob + 3) / 4;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, (const T*)qkv, (T*)o, lse, Tn, J, H, scale, mode, nprob, KP);
+    MBX_LAUNCH_CHECK("attn_fwd");
+    return 0;
+}
+
+extern "C" int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale, int mode,
+                            int dtype, void* stream) {
+    MBX_CHECK_ARG(qkv && o && lse, "attn_fwd: null pointer");
+    if (check_attn_args("attn_fwd", B, T, J, H, hd, mode, dtype)) return 1;
+    const int L = mode == MBX_ATTN_SPATIAL ? J : T;
+    const int nprob = mode == MBX_ATTN_SPATIAL ? B * T * H : B * J * H;
+    const int KP = ((L + 31) / 32) * 32;
+    const bool shared = KP > 32;
+    hipStream_t s = (hipStream_t)stream;
+#define MBX_FWD(TT, HDV)                                                                         \
+    (shared ? launch_fwd<TT, HDV, true>(qkv, o, lse, T, J, H, scale, mode, nprob, KP, s)          \
+            : launch_fwd<TT, HDV, false>(qkv, o, lse, T, J, H, scale, mode, nprob, KP, s))
+    if (dtype == MBX_BF16) return hd == 64 ? MBX_FWD(bf16_t, 64) : MBX_FWD(bf16_t, 32);
+    return hd == 64 ? MBX_FWD(float, 64) : MBX_FWD(float, 32);
+#undef MBX_FWD
+}
+
+template <typename T, int HD, bool SHARED>
+static int launch_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int Tn, int J, int H,
+                      float scale, int mode, int nprob, int KP, hipStream_t s) {
+    constexpr bool IS_BF = sizeof(T) == 2;
+    const int RSTR = rm_stride<T>(HD), TSTR = tr_stride(KP);
+    const size_t per_dq = (size_t)2 * KP * RSTR + (IS_BF ? HD * TSTR : 0);
+    const size_t per_dkv = (size_t)2 * KP * RSTR + (IS_BF ? 2 * HD * TSTR : 0) + 2 * KP * 4;
+    const int grid = SHARED ? nprob : (nprob + 3) / 4;
+    auto k1 = attn_bwd_dq_kernel<T, HD, SHARED>;
+    auto k2 = attn_bwd_dkv_kernel<T, HD, SHARED>;
+    const size_t shm1 = SHARED ? per_dq : 4 * per_dq, shm2 = SHARED ? per_dkv : 4 * per_dkv;
+    if (set_lds(k1, shm1, "attn_bwd_dq") || set_lds(k2, shm2, "attn_bwd_dkv")) return 1;
+    hipLaunchKernelGGL(k1, dim3(grid), dim3(256), shm1, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP);
+    MBX_LAUNCH_CHECK("attn_bwd_dq");
+    hipLaunchKernelGGL(k2, dim3(grid), dim3(256), shm2, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP);
+    MBX_LAUNCH_CHECK("attn_bwd_dkv");
+    return 0;
+}
+
+extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
+                            int H, int hd, float scale, int mode, int dtype, void* stream) {
+    MBX_CHECK_ARG(qkv && o && d_o && lse && dqkv, "attn_bwd: null pointer");
+    if (check_attn_args("attn_bwd", B, T, J, H, hd, mode, dtype)) return 1;
+    const int L = mode == MBX_ATTN_SPATIAL ? J : T;
+    const int nprob = mode == MBX_ATTN_SPATIAL ? B * T * H : B * J * H;
+    const int KP = ((L + 31) / 32) * 32;
+    const bool shared = KP > 32;
+    hipStream_t s = (hipStream_t)stream;
+#define MBX_BWD(TT, HDV)                                                                                             \
+    (shared ? launch_bwd<TT, HDV, true>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s)                   \
+            : launch_bwd<TT, HDV, false>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s))
+    if (dtype == MBX_BF16) return hd == 64 ? MBX_BWD(bf16_t, 64) : MBX_BWD(bf16_t, 32);
+    return hd == 64 ? MBX_BWD(float, 64) : MBX_BWD(float, 32);
+#undef MBX_BWD
+}

@@ -1,0 +1,774 @@
+// Bandwidth-bound kernels of the DSTformer hot path for gfx950: embedding, LayerNorm, adaptive
+// fusion, head, weight preparation and the reduction finalizer.  All of them are "one wave64 per
+// token row" or flat elementwise kernels with 16-byte vector accesses; per-token reductions use
+// wave shuffles (no LDS), parameter-gradient reductions accumulate in registers across a
+// grid-stride loop, reduce across the 4 waves of a block through LDS and leave one partial row
+// per block that colsum_kernel folds deterministically (no atomics).
+#include "mbx_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+int mbx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+extern "C" const char* mbx_last_error(void) { return g_err; }
+extern "C" int mbx_version(void) { return 100; }
+
+static inline int clamp_grid(size_t want, int cap) { return (int)(want < (size_t)cap ? (want ? want : 1) : (size_t)cap); }
+
+// ------------------------------------------------------------------------------------------------
+// colsum finalize: out[c] = sum_p part[p*stride + col0 + c]
+// block = 64 columns x 4 part-groups
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nparts, int stride, int col0,
+                                                     int ncols, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < ncols) {
+        const float* p = part + col0 + c;
+        int i = grp;
+        for (; i + 12 < nparts; i += 16) {
+            s0 += p[(size_t)i * stride];
+            s1 += p[(size_t)(i + 4) * stride];
+            s2 += p[(size_t)(i + 8) * stride];
+            s3 += p[(size_t)(i + 12) * stride];
+        }
+        for (; i < nparts; i += 4) s0 += p[(size_t)i * stride];
+    }
+    red[grp][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && c < ncols) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+int mbx_launch_colsum(const float* part, int nparts, int stride, int col0, int ncols, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, part, nparts, stride, col0, ncols, out);
+    MBX_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight preparation: fp32 [N,K] -> T [N,K] and T [K,N]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weights_kernel(const int64_t* __restrict__ desc) {
+    __shared__ float tile[32][33];
+    const int64_t* d = desc + (size_t)blockIdx.y * 5;
+    const float* src = reinterpret_cast<const float*>(d[0]);
+    T* dst_n = reinterpret_cast<T*>(d[1]);
+    T* dst_t = reinterpret_cast<T*>(d[2]);
+    const int N = (int)d[3], K = (int)d[4];
+    const int tk = (K + 31) / 32, tn = (N + 31) / 32;
+    if ((int)blockIdx.x >= tk * tn) return;
+    const int n0 = (blockIdx.x / tk) * 32, k0 = (blockIdx.x % tk) * 32;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ry + 8 * i;
+        float v = 0.f;
+        if (n0 + r < N && k0 + cx < K) {
+            v = src[(size_t)(n0 + r) * K + k0 + cx];
+            if (dst_n) dst_n[(size_t)(n0 + r) * K + k0 + cx] = Cvt<T>::from_f(v);
+        }
+        tile[r][cx] = v;
+    }
+    __syncthreads();
+    if (dst_t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ry + 8 * i;  // k index within the tile
+            if (k0 + r < K && n0 + cx < N) dst_t[(size_t)(k0 + r) * N + n0 + cx] = Cvt<T>::from_f(tile[cx][r]);
+        }
+    }
+}
+extern "C" int mbx_prep_weights(const int64_t* desc, int n_desc, int max_n, int max_k, int dtype, void* stream) {
+    MBX_CHECK_ARG(desc && n_desc > 0 && max_n > 0 && max_k > 0, "prep_weights: bad arguments");
+    dim3 grid(((max_n + 31) / 32) * ((max_k + 31) / 32), n_desc);
+    if (dtype == MBX_BF16)
+        hipLaunchKernelGGL(prep_weights_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc);
+    else if (dtype == MBX_F32)
+        hipLaunchKernelGGL(prep_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc);
+    else
+        return mbx_set_error("prep_weights: unknown dtype %d", dtype);
+    MBX_LAUNCH_CHECK("prep_weights");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding forward: h[m, c] = sum_k x[m,k] w[c,k] + b[c] + pos[j,c] + temp[t,c]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ pos,
+                                                        const float* __restrict__ temp, float* __restrict__ h, int M,
+                                                        int T, int J, int Din, int C) {
+    const int c4n = C >> 2;
+    const size_t total = (size_t)M * c4n;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / c4n), c = (int)(idx % c4n) * 4;
+        const int j = m % J, t = (m / J) % T;
+        const float4 bb = *reinterpret_cast<const float4*>(b + c);
+        const float4 pp = *reinterpret_cast<const float4*>(pos + (size_t)j * C + c);
+        const float4 tt = *reinterpret_cast<const float4*>(temp + (size_t)t * C + c);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int k = 0; k < Din; ++k) {
+            const float xv = x[(size_t)m * Din + k];
+            a0 = fmaf(xv, w[(size_t)(c + 0) * Din + k], a0);
+            a1 = fmaf(xv, w[(size_t)(c + 1) * Din + k], a1);
+            a2 = fmaf(xv, w[(size_t)(c + 2) * Din + k], a2);
+            a3 = fmaf(xv, w[(size_t)(c + 3) * Din + k], a3);
+        }
+        // same association as the reference: ((xW + b) + pos) + temp
+        *reinterpret_cast<float4*>(h + (size_t)m * C + c) =
+            make_float4(((a0 + bb.x) + pp.x) + tt.x, ((a1 + bb.y) + pp.y) + tt.y, ((a2 + bb.z) + pp.z) + tt.z,
+                        ((a3 + bb.w) + pp.w) + tt.w);
+    }
+}
+extern "C" int mbx_embed_fwd(const float* x, const float* w, const float* b, const float* pos, const float* temp,
+                             float* h, int B, int T, int J, int Din, int C, void* stream) {
+    MBX_CHECK_ARG(x && w && b && pos && temp && h, "embed_fwd: null pointer");
+    MBX_CHECK_ARG(B > 0 && T > 0 && J > 0 && Din > 0 && C > 0 && C % 4 == 0, "embed_fwd: bad shape (C %% 4 != 0?)");
+    const int M = B * T * J;
+    const int grid = clamp_grid(((size_t)M * (C / 4) + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, b, pos, temp, h, M, T, J, Din, C);
+    MBX_LAUNCH_CHECK("embed_fwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding backward.  One block per frame index t: a thread owns channel c and walks (j, b);
+// dtemp[t,c] is final, dpos / dw / db leave one partial row per t (folded by colsum).
+// partial row layout: [J*C | C*Din | C]
+// ------------------------------------------------------------------------------------------------
+#define EMB_MAXDIN 4
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                        float* __restrict__ dtemp, float* __restrict__ part, int B, int T,
+                                                        int J, int Din, int C) {
+    const int t = blockIdx.x;
+    const int stride = J * C + C * Din + C;
+    float* prow = part + (size_t)t * stride;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float at = 0.f, aw[EMB_MAXDIN] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < J; ++j) {
+            float ap = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const size_t m = ((size_t)b * T + t) * J + j;
+                const float g = dh[m * C + c];
+                ap += g;
+#pragma unroll
+                for (int k = 0; k < EMB_MAXDIN; ++k)
+                    if (k < Din) aw[k] = fmaf(g, x[m * Din + k], aw[k]);
+            }
+            prow[(size_t)j * C + c] = ap;
+            at += ap;
+        }
+        dtemp[(size_t)t * C + c] = at;
+#pragma unroll
+        for (int k = 0; k < EMB_MAXDIN; ++k)
+            if (k < Din) prow[(size_t)J * C + (size_t)c * Din + k] = aw[k];
+        prow[(size_t)J * C + (size_t)C * Din + c] = at;
+    }
+}
+// dx[m,k] = sum_c dh[m,c] w[c,k]  (one wave per token)
+__global__ __launch_bounds__(256) void embed_bwd_dx_kernel(const float* __restrict__ dh, const float* __restrict__ w,
+                                                           float* __restrict__ dx, int M, int Din, int C) {
+    const int lane = threadIdx.x & 63;
+    for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
+        float a[EMB_MAXDIN] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < C; c += 64) {
+            const float g = dh[(size_t)m * C + c];
+#pragma unroll
+            for (int k = 0; k < EMB_MAXDIN; ++k)
+                if (k < Din) a[k] = fmaf(g, w[(size_t)c * Din + k], a[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < EMB_MAXDIN; ++k) {
+            const float s = wave_sum(a[k]);
+            if (lane == 0 && k < Din) dx[(size_t)m * Din + k] = s;
+        }
+    }
+}
+extern "C" size_t mbx_embed_bwd_ws(int T, int J, int Din, int C) { return (size_t)T * ((size_t)J * C + (size_t)C * Din + C) * sizeof(float); }
+extern "C" int mbx_embed_bwd(const float* dh, const float* x, const float* w, float* dw, float* db, float* dpos,
+                             float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream) {
+    MBX_CHECK_ARG(dh && x && w && dw && db && dpos && dtemp && ws, "embed_bwd: null pointer");
+    MBX_CHECK_ARG(Din <= EMB_MAXDIN, "embed_bwd: dim_in %d > %d unsupported", Din, EMB_MAXDIN);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const int stride = J * C + C * Din + C;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(T), dim3(256), 0, s, dh, x, dtemp, part, B, T, J, Din, C);
+    MBX_LAUNCH_CHECK("embed_bwd");
+    if (mbx_launch_colsum(part, T, stride, 0, J * C, dpos, s)) return 1;
+    if (mbx_launch_colsum(part, T, stride, J * C, C * Din, dw, s)) return 1;
+    if (mbx_launch_colsum(part, T, stride, J * C + C * Din, C, db, s)) return 1;
+    if (dx) {
+        const int M = B * T * J;
+        hipLaunchKernelGGL(embed_bwd_dx_kernel, dim3(clamp_grid((M + 3) / 4, 2048)), dim3(256), 0, s, dh, w, dx, M, Din, C);
+        MBX_LAUNCH_CHECK("embed_bwd_dx");
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-per-wave helpers: a lane owns VPL float4 slots at channel c = (k*64 + lane)*4
+// ------------------------------------------------------------------------------------------------
+#define ROW_LOOP(k) _Pragma("unroll") for (int k = 0; k < VPL; ++k)
+#define ROW_C(k) (((k) * 64 + lane) * 4)
+
+static inline int vpl_for(int C) { return C <= 256 ? 1 : C <= 512 ? 2 : C <= 1024 ? 4 : C <= 2048 ? 8 : 0; }
+#define DISPATCH_VPL(vpl, ...)           \
+    switch (vpl) {                       \
+        case 1: { constexpr int VPL = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int VPL = 2; __VA_ARGS__; } break; \
+        case 4: { constexpr int VPL = 4; __VA_ARGS__; } break; \
+        case 8: { constexpr int VPL = 8; __VA_ARGS__; } break; \
+        default: return mbx_set_error("row kernel: channel count unsupported (need C %% 4 == 0 and C <= 2048)"); \
+    }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int C) {
+    const int lane = threadIdx.x & 63;
+    float g[VPL][4], bt[VPL][4];
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (c < C) { load4<float>(gamma + c, g[k]); load4<float>(beta + c, bt[k]); }
+    }
+    const float invC = 1.0f / (float)C;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        float v[VPL][4];
+        float s = 0.f;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) { load4<float>(x + (size_t)row * C + c, v[k]); s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]); }
+        }
+        const float mu = wave_sum(s) * invC;
+        float q = 0.f;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[k][i] -= mu; q = fmaf(v[k][i], v[k][i], q); }
+            }
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = fmaf(v[k][i] * rs, g[k][i], bt[k][i]);
+                store4<T>(y + (size_t)row * C + c, o);
+            }
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+extern "C" int mbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                                 float* rstd, int M, int C, int dtype, void* stream) {
+    MBX_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "layernorm_fwd: bad shape M=%d C=%d", M, C);
+    const int grid = clamp_grid((M + 3) / 4, 256 * 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MBX_BF16) {
+        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, VPL>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (bf16_t*)y, mean, rstd, M, C));
+    } else if (dtype == MBX_F32) {
+        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((ln_fwd_kernel<float, VPL>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (float*)y, mean, rstd, M, C));
+    } else {
+        return mbx_set_error("layernorm_fwd: unknown dtype %d", dtype);
+    }
+    MBX_LAUNCH_CHECK("layernorm_fwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-level fold of per-wave register partials: wave w writes acc to lds[w][...], then the block
+// sums the 4 waves and writes one partial row.  n = floats per wave.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_fold_store(const float* lds /*[4][n]*/, int n, float* __restrict__ dst) {
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = (lds[i] + lds[n + i]) + (lds[2 * n + i] + lds[3 * n + i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward (+ residual-gradient add, + T copy for the next GEMM)
+// partial row layout: [dgamma C | dbeta C]
+// ------------------------------------------------------------------------------------------------
+#define LN_BWD_BLOCKS 512
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     const float* __restrict__ extra, float* __restrict__ dx,
+                                                     T* __restrict__ dx_t, float* __restrict__ part, int M, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[VPL][4], ag[VPL][4], ab[VPL][4];
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ag[k][i] = 0.f; ab[k][i] = 0.f; g[k][i] = 0.f; }
+        if (c < C) load4<float>(gamma + c, g[k]);
+    }
+    const float invC = 1.0f / (float)C;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float d[VPL][4], xh[VPL][4];
+        float s1 = 0.f, s2 = 0.f;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) {
+                load4<T>(dy + (size_t)row * C + c, d[k]);
+                load4<float>(x + (size_t)row * C + c, xh[k]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xh[k][i] = (xh[k][i] - mu) * rs;
+                    ag[k][i] = fmaf(d[k][i], xh[k][i], ag[k][i]);
+                    ab[k][i] += d[k][i];
+                    d[k][i] *= g[k][i];
+                    s1 += d[k][i];
+                    s2 = fmaf(d[k][i], xh[k][i], s2);
+                }
+            }
+        }
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) {
+                float r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = rs * (d[k][i] - s1 - xh[k][i] * s2);
+                if (dres) {
+                    float t[4];
+                    load4<float>(dres + (size_t)row * C + c, t);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] += t[i];
+                }
+                if (extra) {
+                    float t[4];
+                    load4<float>(extra + (size_t)row * C + c, t);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] += t[i];
+                }
+                store4<float>(dx + (size_t)row * C + c, r);
+                if (dx_t) store4<T>(dx_t + (size_t)row * C + c, r);
+            }
+        }
+    }
+    float* mine = lds + (size_t)wave * 2 * C;
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (c < C) { store4<float>(mine + c, ag[k]); store4<float>(mine + C + c, ab[k]); }
+    }
+    __syncthreads();
+    block_fold_store(lds, 2 * C, part + (size_t)blockIdx.x * 2 * C);
+}
+extern "C" size_t mbx_layernorm_bwd_ws(int C) { return (size_t)LN_BWD_BLOCKS * 2 * C * sizeof(float); }
+extern "C" int mbx_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* dres, const float* extra, float* dx, void* dx_t, float* dgamma, float* dbeta,
+                                 int M, int C, int dtype, void* ws, void* stream) {
+    MBX_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape M=%d C=%d", M, C);
+    const int grid = clamp_grid((M + 3) / 4, LN_BWD_BLOCKS);
+    const size_t shm = (size_t)4 * 2 * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    if (dtype == MBX_BF16) {
+        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, VPL>), dim3(grid), dim3(256), shm, s, (const bf16_t*)dy, x, mean, rstd, gamma, dres, extra, dx, (bf16_t*)dx_t, part, M, C));
+    } else if (dtype == MBX_F32) {
+        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((ln_bwd_kernel<float, VPL>), dim3(grid), dim3(256), shm, s, (const float*)dy, x, mean, rstd, gamma, dres, extra, dx, (float*)dx_t, part, M, C));
+    } else {
+        return mbx_set_error("layernorm_bwd: unknown dtype %d", dtype);
+    }
+    MBX_LAUNCH_CHECK("layernorm_bwd");
+    if (mbx_launch_colsum(part, grid, 2 * C, 0, C, dgamma, s)) return 1;
+    if (mbx_launch_colsum(part, grid, 2 * C, C, C, dbeta, s)) return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive fusion forward
+// ------------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(const float* __restrict__ x_st, const float* __restrict__ x_ts,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       float* __restrict__ out, float* __restrict__ alpha, int M, int C) {
+    const int lane = threadIdx.x & 63;
+    float w0s[VPL][4], w0t[VPL][4], w1s[VPL][4], w1t[VPL][4];
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (c < C) {
+            load4<float>(w + c, w0s[k]); load4<float>(w + C + c, w0t[k]);
+            load4<float>(w + 2 * C + c, w1s[k]); load4<float>(w + 3 * C + c, w1t[k]);
+        }
+    }
+    const float b0 = b[0], b1 = b[1];
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        float a[VPL][4], t[VPL][4];
+        float l0 = 0.f, l1 = 0.f;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) {
+                load4<float>(x_st + (size_t)row * C + c, a[k]);
+                load4<float>(x_ts + (size_t)row * C + c, t[k]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    l0 = fmaf(a[k][i], w0s[k][i], fmaf(t[k][i], w0t[k][i], l0));
+                    l1 = fmaf(a[k][i], w1s[k][i], fmaf(t[k][i], w1t[k][i], l1));
+                }
+            }
+        }
+        l0 = wave_sum(l0) + b0;
+        l1 = wave_sum(l1) + b1;
+        const float mx = fmaxf(l0, l1);
+        const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
+        const float inv = 1.0f / (e0 + e1);
+        const float a0 = e0 * inv, a1 = e1 * inv;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = fmaf(a[k][i], a0, t[k][i] * a1);
+                store4<float>(out + (size_t)row * C + c, o);
+            }
+        }
+        if (lane == 0) { alpha[(size_t)row * 2] = a0; alpha[(size_t)row * 2 + 1] = a1; }
+    }
+}
+extern "C" int mbx_fuse_fwd(const float* x_st, const float* x_ts, const float* w, const float* b, float* out,
+                            float* alpha, int M, int C, void* stream) {
+    MBX_CHECK_ARG(x_st && x_ts && w && b && out && alpha, "fuse_fwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "fuse_fwd: bad shape");
+    const int grid = clamp_grid((M + 3) / 4, 256 * 8);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((fuse_fwd_kernel<VPL>), dim3(grid), dim3(256), 0, s, x_st, x_ts, w, b, out, alpha, M, C));
+    MBX_LAUNCH_CHECK("fuse_fwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive fusion backward.  partial row layout: [dw 4C | db 2 | pad 2]
+// ------------------------------------------------------------------------------------------------
+#define FUSE_BWD_BLOCKS 512
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x_st,
+                                                       const float* __restrict__ x_ts, const float* __restrict__ alpha,
+                                                       const float* __restrict__ w, float* __restrict__ d_st,
+                                                       float* __restrict__ d_ts, T* __restrict__ d_st_t,
+                                                       T* __restrict__ d_ts_t, float* __restrict__ part, int M, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = 4 * C + 4;
+    float w0s[VPL][4], w0t[VPL][4], w1s[VPL][4], w1t[VPL][4];
+    float g0s[VPL][4], g0t[VPL][4], g1s[VPL][4], g1t[VPL][4];
+    float gb0 = 0.f, gb1 = 0.f;
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { g0s[k][i] = g0t[k][i] = g1s[k][i] = g1t[k][i] = 0.f; w0s[k][i] = w0t[k][i] = w1s[k][i] = w1t[k][i] = 0.f; }
+        if (c < C) {
+            load4<float>(w + c, w0s[k]); load4<float>(w + C + c, w0t[k]);
+            load4<float>(w + 2 * C + c, w1s[k]); load4<float>(w + 3 * C + c, w1t[k]);
+        }
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float a0 = alpha[(size_t)row * 2], a1 = alpha[(size_t)row * 2 + 1];
+        float d[VPL][4], a[VPL][4], t[VPL][4];
+        float da0 = 0.f, da1 = 0.f;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) {
+                load4<float>(dh + (size_t)row * C + c, d[k]);
+                load4<float>(x_st + (size_t)row * C + c, a[k]);
+                load4<float>(x_ts + (size_t)row * C + c, t[k]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { da0 = fmaf(d[k][i], a[k][i], da0); da1 = fmaf(d[k][i], t[k][i], da1); }
+            }
+        }
+        da0 = wave_sum(da0);
+        da1 = wave_sum(da1);
+        const float dot = da0 * a0 + da1 * a1;
+        const float dl0 = a0 * (da0 - dot), dl1 = a1 * (da1 - dot);
+        gb0 += dl0;
+        gb1 += dl1;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < C) {
+                float rs[4], rt[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rs[i] = fmaf(d[k][i], a0, fmaf(dl0, w0s[k][i], dl1 * w1s[k][i]));
+                    rt[i] = fmaf(d[k][i], a1, fmaf(dl0, w0t[k][i], dl1 * w1t[k][i]));
+                    g0s[k][i] = fmaf(dl0, a[k][i], g0s[k][i]);
+                    g0t[k][i] = fmaf(dl0, t[k][i], g0t[k][i]);
+                    g1s[k][i] = fmaf(dl1, a[k][i], g1s[k][i]);
+                    g1t[k][i] = fmaf(dl1, t[k][i], g1t[k][i]);
+                }
+                store4<float>(d_st + (size_t)row * C + c, rs);
+                store4<float>(d_ts + (size_t)row * C + c, rt);
+                store4<T>(d_st_t + (size_t)row * C + c, rs);
+                store4<T>(d_ts_t + (size_t)row * C + c, rt);
+            }
+        }
+    }
+    float* mine = lds + (size_t)wave * n;
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (c < C) {
+            store4<float>(mine + c, g0s[k]); store4<float>(mine + C + c, g0t[k]);
+            store4<float>(mine + 2 * C + c, g1s[k]); store4<float>(mine + 3 * C + c, g1t[k]);
+        }
+    }
+    if (lane == 0) { mine[4 * C] = gb0; mine[4 * C + 1] = gb1; mine[4 * C + 2] = 0.f; mine[4 * C + 3] = 0.f; }
+    __syncthreads();
+    block_fold_store(lds, n, part + (size_t)blockIdx.x * n);
+}
+extern "C" size_t mbx_fuse_bwd_ws(int C) { return (size_t)FUSE_BWD_BLOCKS * (4 * (size_t)C + 4) * sizeof(float); }
+extern "C" int mbx_fuse_bwd(const float* dh, const float* x_st, const float* x_ts, const float* alpha, const float* w,
+                            float* d_st, float* d_ts, void* d_st_t, void* d_ts_t, float* dw, float* db, int M, int C,
+                            int dtype, void* ws, void* stream) {
+    MBX_CHECK_ARG(dh && x_st && x_ts && alpha && w && d_st && d_ts && d_st_t && d_ts_t && dw && db && ws, "fuse_bwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "fuse_bwd: bad shape");
+    const int grid = clamp_grid((M + 3) / 4, FUSE_BWD_BLOCKS);
+    const int n = 4 * C + 4;
+    const size_t shm = (size_t)4 * n * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    if (dtype == MBX_BF16) {
+        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((fuse_bwd_kernel<bf16_t, VPL>), dim3(grid), dim3(256), shm, s, dh, x_st, x_ts, alpha, w, d_st, d_ts, (bf16_t*)d_st_t, (bf16_t*)d_ts_t, part, M, C));
+    } else if (dtype == MBX_F32) {
+        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((fuse_bwd_kernel<float, VPL>), dim3(grid), dim3(256), shm, s, dh, x_st, x_ts, alpha, w, d_st, d_ts, (float*)d_st_t, (float*)d_ts_t, part, M, C));
+    } else {
+        return mbx_set_error("fuse_bwd: unknown dtype %d", dtype);
+    }
+    MBX_LAUNCH_CHECK("fuse_bwd");
+    if (mbx_launch_colsum(part, grid, n, 0, 4 * C, dw, s)) return 1;
+    if (mbx_launch_colsum(part, grid, n, 4 * C, 2, db, s)) return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// att_fuse=False: plain average and its backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void average_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4((u.x + v.x) * 0.5f, (u.y + v.y) * 0.5f, (u.z + v.z) * 0.5f, (u.w + v.w) * 0.5f);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void average_bwd_kernel(const float* __restrict__ dh, float* __restrict__ d_st,
+                                                          float* __restrict__ d_ts, T* __restrict__ d_st_t,
+                                                          T* __restrict__ d_ts_t, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float v[4];
+        load4<float>(dh + i * 4, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= 0.5f;
+        store4<float>(d_st + i * 4, v);
+        store4<float>(d_ts + i * 4, v);
+        store4<T>(d_st_t + i * 4, v);
+        store4<T>(d_ts_t + i * 4, v);
+    }
+}
+extern "C" int mbx_average(const float* x_st, const float* x_ts, float* out, size_t n, void* stream) {
+    MBX_CHECK_ARG(x_st && x_ts && out && n % 4 == 0, "average: bad arguments");
+    hipLaunchKernelGGL(average_kernel, dim3(clamp_grid((n / 4 + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, x_st, x_ts, out, n / 4);
+    MBX_LAUNCH_CHECK("average");
+    return 0;
+}
+extern "C" int mbx_average_bwd(const float* dh, float* d_st, float* d_ts, void* d_st_t, void* d_ts_t, size_t n,
+                               int dtype, void* stream) {
+    MBX_CHECK_ARG(dh && d_st && d_ts && d_st_t && d_ts_t && n % 4 == 0, "average_bwd: bad arguments");
+    const int grid = clamp_grid((n / 4 + 255) / 256, 4096);
+    if (dtype == MBX_BF16)
+        hipLaunchKernelGGL(average_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dh, d_st, d_ts, (bf16_t*)d_st_t, (bf16_t*)d_ts_t, n / 4);
+    else if (dtype == MBX_F32)
+        hipLaunchKernelGGL(average_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dh, d_st, d_ts, (float*)d_st_t, (float*)d_ts_t, n / 4);
+    else
+        return mbx_set_error("average_bwd: unknown dtype %d", dtype);
+    MBX_LAUNCH_CHECK("average_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: Linear(R -> Dout), Dout <= 8 (skinny: VALU dot products, wave reduction)
+// ------------------------------------------------------------------------------------------------
+#define HEAD_MAXD 8
+template <int VPL>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ rep, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ out, int M, int R,
+                                                       int Dout) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        float v[VPL][4];
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < R) load4<float>(rep + (size_t)row * R + c, v[k]);
+        }
+        float mine = 0.f;
+        for (int i = 0; i < Dout; ++i) {
+            float a = 0.f;
+            ROW_LOOP(k) {
+                const int c = ROW_C(k);
+                if (c < R) {
+                    float ww[4];
+                    load4<float>(w + (size_t)i * R + c, ww);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = fmaf(v[k][e], ww[e], a);
+                }
+            }
+            a = wave_sum(a) + b[i];
+            if (lane == i) mine = a;
+        }
+        if (lane < Dout) out[(size_t)row * Dout + lane] = mine;
+    }
+}
+extern "C" int mbx_head_fwd(const float* rep, const float* w, const float* b, float* out, int M, int R, int Dout,
+                            void* stream) {
+    MBX_CHECK_ARG(rep && w && b && out, "head_fwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && R % 4 == 0 && Dout >= 1 && Dout <= HEAD_MAXD, "head_fwd: need R %% 4 == 0 and 1 <= dim_out <= %d", HEAD_MAXD);
+    const int grid = clamp_grid((M + 3) / 4, 256 * 8);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_VPL(vpl_for(R), hipLaunchKernelGGL((head_fwd_kernel<VPL>), dim3(grid), dim3(256), 0, s, rep, w, b, out, M, R, Dout));
+    MBX_LAUNCH_CHECK("head_fwd");
+    return 0;
+}
+
+// head backward: dpre = (dout . w) * (1 - rep^2); partial row layout: [dw Dout*R | db 8]
+#define HEAD_BWD_BLOCKS 512
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ rep,
+                                                       const float* __restrict__ w, T* __restrict__ dpre,
+                                                       float* __restrict__ part, int M, int R, int Dout) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = Dout * R + 8;
+    // zero this wave's LDS accumulator rows (dw accumulates in LDS-free registers per output i below)
+    float* mine = lds + (size_t)wave * n;
+    float gb[HEAD_MAXD];
+#pragma unroll
+    for (int i = 0; i < HEAD_MAXD; ++i) gb[i] = 0.f;
+    for (int i = 0; i < Dout; ++i) {
+        // one output channel at a time keeps the register footprint independent of Dout
+        float ww[VPL][4], gw[VPL][4];
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gw[k][e] = 0.f; ww[k][e] = 0.f; }
+            if (c < R) load4<float>(w + (size_t)i * R + c, ww[k]);
+        }
+        float gbi = 0.f;
+        for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+            const float dv = dout[(size_t)row * Dout + i];
+            gbi += dv;
+            ROW_LOOP(k) {
+                const int c = ROW_C(k);
+                if (c < R) {
+                    float r[4];
+                    load4<float>(rep + (size_t)row * R + c, r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gw[k][e] = fmaf(dv, r[e], gw[k][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < HEAD_MAXD; ++q)
+            if (q == i) gb[q] = gbi;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < R) store4<float>(mine + (size_t)i * R + c, gw[k]);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < HEAD_MAXD; ++q) mine[Dout * R + q] = gb[q];
+    }
+    // dpre: one pass over the rows with all Dout weights
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        float dv[HEAD_MAXD];
+#pragma unroll
+        for (int q = 0; q < HEAD_MAXD; ++q) dv[q] = q < Dout ? dout[(size_t)row * Dout + q] : 0.f;
+        ROW_LOOP(k) {
+            const int c = ROW_C(k);
+            if (c < R) {
+                float r[4], o[4] = {0.f, 0.f, 0.f, 0.f};
+                load4<float>(rep + (size_t)row * R + c, r);
+#pragma unroll
+                for (int q = 0; q < HEAD_MAXD; ++q) {
+                    if (q < Dout) {
+                        float ww[4];
+                        load4<float>(w + (size_t)q * R + c, ww);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaf(dv[q], ww[e], o[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= (1.0f - r[e] * r[e]);
+                store4<T>(dpre + (size_t)row * R + c, o);
+            }
+        }
+    }
+    __syncthreads();
+    block_fold_store(lds, n, part + (size_t)blockIdx.x * n);
+}
+extern "C" size_t mbx_head_bwd_ws(int R, int Dout) { return (size_t)HEAD_BWD_BLOCKS * ((size_t)Dout * R + 8) * sizeof(float); }
+extern "C" int mbx_head_bwd(const float* dout, const float* rep, const float* w, void* dpre_t, float* dw, float* db,
+                            int M, int R, int Dout, int dtype, void* ws, void* stream) {
+    MBX_CHECK_ARG(dout && rep && w && dpre_t && dw && db && ws, "head_bwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && R % 4 == 0 && Dout >= 1 && Dout <= HEAD_MAXD, "head_bwd: need R %% 4 == 0 and 1 <= dim_out <= %d", HEAD_MAXD);
+    const int grid = clamp_grid((M + 3) / 4, HEAD_BWD_BLOCKS);
+    const int n = Dout * R + 8;
+    const size_t shm = (size_t)4 * n * sizeof(float);
+    MBX_CHECK_ARG(shm <= 160 * 1024, "head_bwd: dim_out*dim_rep too large for the LDS fold");
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    if (dtype == MBX_BF16) {
+        DISPATCH_VPL(vpl_for(R), hipLaunchKernelGGL((head_bwd_kernel<bf16_t, VPL>), dim3(grid), dim3(256), shm, s, dout, rep, w, (bf16_t*)dpre_t, part, M, R, Dout));
+    } else if (dtype == MBX_F32) {
+        DISPATCH_VPL(vpl_for(R), hipLaunchKernelGGL((head_bwd_kernel<float, VPL>), dim3(grid), dim3(256), shm, s, dout, rep, w, (float*)dpre_t, part, M, R, Dout));
+    } else {
+        return mbx_set_error("head_bwd: unknown dtype %d", dtype);
+    }
+    MBX_LAUNCH_CHECK("head_bwd");
+    if (mbx_launch_colsum(part, grid, n, 0, Dout * R, dw, s)) return 1;
+    if (mbx_launch_colsum(part, grid, n, Dout * R, Dout, db, s)) return 1;
+    return 0;
+}
+
+// tanh backward on the representation path: dpre = drep * (1 - rep^2)
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ drep, const float* __restrict__ rep,
+                                                       T* __restrict__ dpre, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float d[4], r[4];
+        load4<float>(drep + i * 4, d);
+        load4<float>(rep + i * 4, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] *= (1.0f - r[k] * r[k]);
+        store4<T>(dpre + i * 4, d);
+    }
+}
+extern "C" int mbx_tanh_bwd(const float* drep, const float* rep, void* dpre_t, size_t n, int dtype, void* stream) {
+    MBX_CHECK_ARG(drep && rep && dpre_t && n % 4 == 0, "tanh_bwd: bad arguments");
+    const int grid = clamp_grid((n / 4 + 255) / 256, 4096);
+    if (dtype == MBX_BF16)
+        hipLaunchKernelGGL(tanh_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, drep, rep, (bf16_t*)dpre_t, n / 4);
+    else if (dtype == MBX_F32)
+        hipLaunchKernelGGL(tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, drep, rep, (float*)dpre_t, n / 4);
+    else
+        return mbx_set_error("tanh_bwd: unknown dtype %d", dtype);
+    MBX_LAUNCH_CHECK("tanh_bwd");
+    return 0;
+}

@@ -1,0 +1,88 @@
+// Shared device/host helpers for the gfx950 kernel set of libmbx.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mbx.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits (the C ABI passes void*; T is chosen by `dtype`)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA bf16 A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define MBX_WAVE 64
+
+// ---------------------------------------------------------------- error plumbing (thread-local)
+int mbx_set_error(const char* fmt, ...);
+#define MBX_CHECK_ARG(cond, ...)                    \
+    do {                                            \
+        if (!(cond)) return mbx_set_error(__VA_ARGS__); \
+    } while (0)
+#define MBX_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) return mbx_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, quiet NaN
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    static __device__ __forceinline__ float to_f(float v) { return v; }
+    static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+    static __device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+    static __device__ __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
+};
+
+// 4 consecutive T elements <-> float[4] (16-B / 8-B vector access; pointers must be aligned to 4 elements)
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+
+// ---------------------------------------------------------------- wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- activation math (fp32)
+__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float u) {
+    return 0.5f * (1.0f + erff(u * 0.70710678118654752440f)) + u * __expf(-0.5f * u * u) * 0.39894228040143267794f;
+}
+
+// ---------------------------------------------------------------- column-sum finalize (shared by all reductions)
+// out[c] = sum_{p < nparts} part[p * stride + col0 + c],  c < ncols
+int mbx_launch_colsum(const float* part, int nparts, int stride, int col0, int ncols, float* out, hipStream_t s);

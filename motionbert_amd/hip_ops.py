@@ -1,0 +1,232 @@
+"""ctypes binding of libmbx.so: the kernel provider (`ops`) used by motionbert_amd.engine.
+
+Thin by design: every method checks nothing but dtypes/contiguity, takes raw device pointers from
+the torch tensors (PyTorch owns all memory), passes the current HIP stream and raises
+RuntimeError(mbx_last_error()) on a non-zero return.  There is no CPU implementation and no
+fallback: if libmbx.so cannot be loaded the import of this module's `get()` fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Dict, List, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmbx.so')
+
+MBX_F32, MBX_BF16 = 0, 1
+_DT = {torch.float32: MBX_F32, torch.bfloat16: MBX_BF16}
+
+_vp, _i, _f, _sz, _i64p = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/mbx.h one to one
+SIGNATURES = {
+    'mbx_last_error': (C.c_char_p, []),
+    'mbx_version': (_i, []),
+    'mbx_prep_weights': (_i, [_i64p, _i, _i, _i, _i, _vp]),
+    'mbx_embed_fwd': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
+    'mbx_embed_bwd_ws': (_sz, [_i] * 4),
+    'mbx_embed_bwd': (_i, [_vp] * 8 + [_i] * 5 + [_vp, _vp]),
+    'mbx_layernorm_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'mbx_layernorm_bwd_ws': (_sz, [_i]),
+    'mbx_layernorm_bwd': (_i, [_vp] * 11 + [_i, _i, _i, _vp, _vp]),
+    'mbx_gemm_nt': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mbx_gemm_tn_ws': (_sz, [_i, _i, _i]),
+    'mbx_gemm_tn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'mbx_attn_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'mbx_attn_bwd': (_i, [_vp] * 5 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'mbx_fuse_fwd': (_i, [_vp] * 6 + [_i, _i, _vp]),
+    'mbx_fuse_bwd_ws': (_sz, [_i]),
+    'mbx_fuse_bwd': (_i, [_vp] * 11 + [_i, _i, _i, _vp, _vp]),
+    'mbx_average': (_i, [_vp, _vp, _vp, _sz, _vp]),
+    'mbx_average_bwd': (_i, [_vp] * 5 + [_sz, _i, _vp]),
+    'mbx_head_fwd': (_i, [_vp] * 4 + [_i, _i, _i, _vp]),
+    'mbx_head_bwd_ws': (_sz, [_i, _i]),
+    'mbx_head_bwd': (_i, [_vp] * 6 + [_i, _i, _i, _i, _vp, _vp]),
+    'mbx_tanh_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+}
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen libmbx.so and attach the prototypes.  Works without a GPU (symbols only)."""
+    if not os.path.exists(path):
+        raise RuntimeError(f'{path} not found: build it with `python -m motionbert_amd.build` '
+                           '(hipcc --offload-arch=gfx950); there is no fallback implementation')
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipOps:
+    """Kernel provider backed by libmbx.so.  Stateless apart from size caches."""
+
+    def __init__(self, lib: Optional[C.CDLL] = None):
+        self.lib = lib or load_library()
+        self._ws_cache: Dict[tuple, int] = {}
+        self._desc_cache: Dict[tuple, dict] = {}
+        self._lock = threading.Lock()
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise RuntimeError('libmbx: ' + self.lib.mbx_last_error().decode())
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _ws(self, key: tuple, fn, *args, device=None) -> torch.Tensor:
+        n = self._ws_cache.get(key)
+        if n is None:
+            n = int(fn(*args))
+            self._ws_cache[key] = n
+        return torch.empty(max(n, 16), dtype=torch.uint8, device=device)
+
+    # ------------------------------------------------------------------ weights
+    def prep_weights(self, P: Dict[str, torch.Tensor], names: List[str], tdtype, need_t: bool):
+        """T-typed copies of every Linear weight: Wn[name] [N,K] and (for backward) Wt[name] [K,N]."""
+        ws = [P[n + '.weight'] for n in names]
+        dev = ws[0].device
+        dt = _DT[tdtype]
+        key = (tuple(w.data_ptr() for w in ws), dt, dev.index)
+        with self._lock:
+            ent = self._desc_cache.get(key)
+            if ent is None:
+                offs, rows, off = [], [], 0
+                for w in ws:
+                    N, K = w.shape
+                    rows.append([w.data_ptr(), 0, 0, N, K])
+                    offs.append(off)
+                    off += N * K
+                if len(self._desc_cache) > 64:
+                    self._desc_cache.clear()
+                ent = dict(desc=torch.tensor(rows, dtype=torch.int64).to(dev),
+                           offs=(torch.tensor(offs, dtype=torch.int64) * torch.empty(0, dtype=tdtype).element_size()).to(dev),
+                           offs_host=offs, total=off, max_n=max(w.shape[0] for w in ws), max_k=max(w.shape[1] for w in ws))
+                self._desc_cache[key] = ent
+        for w in ws:
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise RuntimeError('libmbx: parameters must be contiguous fp32')
+        desc = ent['desc'].clone()
+        make_n = tdtype != torch.float32          # fp32 mode reads the parameters in place
+        flat_n = torch.empty(ent['total'], dtype=tdtype, device=dev) if make_n else None
+        flat_t = torch.empty(ent['total'], dtype=tdtype, device=dev) if need_t else None
+        if make_n:
+            desc[:, 1] = ent['offs'] + flat_n.data_ptr()
+        if need_t:
+            desc[:, 2] = ent['offs'] + flat_t.data_ptr()
+        if make_n or need_t:
+            self._ck(self.lib.mbx_prep_weights(desc.data_ptr(), len(ws), ent['max_n'], ent['max_k'], dt, self._stream()))
+        Wn, Wt = {}, {}
+        for n, w, off in zip(names, ws, ent['offs_host']):
+            N, K = w.shape
+            Wn[n] = flat_n[off:off + N * K].view(N, K) if make_n else w.detach()
+            if need_t:
+                Wt[n] = flat_t[off:off + N * K].view(K, N)
+        return Wn, Wt
+
+    # ------------------------------------------------------------------ embedding
+    def embed_fwd(self, x, w, b, pos, temp, h, B, T, J):
+        self._ck(self.lib.mbx_embed_fwd(_p(x), _p(w), _p(b), _p(pos), _p(temp), _p(h), B, T, J, x.shape[-1], h.shape[-1],
+                                        self._stream()))
+
+    def embed_bwd(self, dh, x, w, dw, db, dpos, dtemp, dx, B, T, J):
+        Din, Cc = x.shape[-1], dh.shape[-1]
+        ws = self._ws(('emb', T, J, Din, Cc), self.lib.mbx_embed_bwd_ws, T, J, Din, Cc, device=dh.device)
+        dtemp.zero_()
+        self._ck(self.lib.mbx_embed_bwd(_p(dh), _p(x), _p(w), _p(dw), _p(db), _p(dpos), _p(dtemp), _p(dx), B, T, J, Din, Cc,
+                                        _p(ws), self._stream()))
+
+    # ------------------------------------------------------------------ layernorm
+    def layernorm_fwd(self, x, g, b, eps, y_t, mean, rstd):
+        M, Cc = x.shape
+        self._ck(self.lib.mbx_layernorm_fwd(_p(x), _p(g), _p(b), float(eps), _p(y_t), _p(mean), _p(rstd), M, Cc,
+                                            _DT[y_t.dtype], self._stream()))
+
+    def layernorm_bwd(self, dy_t, x, mean, rstd, g, dres, extra, dx, dx_t, dg, db):
+        M, Cc = x.shape
+        ws = self._ws(('lnb', Cc), self.lib.mbx_layernorm_bwd_ws, Cc, device=x.device)
+        self._ck(self.lib.mbx_layernorm_bwd(_p(dy_t), _p(x), _p(mean), _p(rstd), _p(g), _p(dres), _p(extra), _p(dx), _p(dx_t),
+                                            _p(dg), _p(db), M, Cc, _DT[dy_t.dtype], _p(ws), self._stream()))
+
+    # ------------------------------------------------------------------ GEMMs
+    def gemm_nt(self, a_t, w_t, bias, epi, out_t=None, out2_t=None, out_f=None, resid=None, aux_t=None):
+        M, K = a_t.shape
+        N = w_t.shape[0]
+        if w_t.shape[1] != K or a_t.dtype != w_t.dtype:
+            raise RuntimeError(f'libmbx: gemm_nt operand mismatch {tuple(a_t.shape)} {a_t.dtype} x {tuple(w_t.shape)} {w_t.dtype}')
+        self._ck(self.lib.mbx_gemm_nt(_p(a_t), _p(w_t), _p(bias), int(epi), _p(out_t), _p(out2_t), _p(out_f), _p(resid),
+                                      _p(aux_t), M, N, K, _DT[a_t.dtype], self._stream()))
+
+    def gemm_tn(self, dy_t, a_t, dw, db):
+        M, N = dy_t.shape
+        K = a_t.shape[1]
+        ws = self._ws(('tn', M, N, K), self.lib.mbx_gemm_tn_ws, M, N, K, device=dy_t.device)
+        self._ck(self.lib.mbx_gemm_tn(_p(dy_t), _p(a_t), _p(dw), _p(db), M, N, K, _DT[dy_t.dtype], _p(ws), self._stream()))
+
+    # ------------------------------------------------------------------ attention
+    def attn_fwd(self, qkv, o, lse, B, T, J, H, scale, mode):
+        hd = o.shape[-1] // H
+        self._ck(self.lib.mbx_attn_fwd(_p(qkv), _p(o), _p(lse), B, T, J, H, hd, float(scale), int(mode), _DT[qkv.dtype],
+                                       self._stream()))
+
+    def attn_bwd(self, qkv, o, do, lse, dqkv, B, T, J, H, scale, mode):
+        hd = o.shape[-1] // H
+        self._ck(self.lib.mbx_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, J, H, hd, float(scale), int(mode),
+                                       _DT[qkv.dtype], self._stream()))
+
+    # ------------------------------------------------------------------ fusion
+    def fuse_fwd(self, x_st, x_ts, w, b, out, alpha):
+        M, Cc = x_st.shape
+        self._ck(self.lib.mbx_fuse_fwd(_p(x_st), _p(x_ts), _p(w), _p(b), _p(out), _p(alpha), M, Cc, self._stream()))
+
+    def fuse_bwd(self, dh, x_st, x_ts, alpha, w, d_st, d_ts, d_st_t, d_ts_t, dw, db):
+        M, Cc = x_st.shape
+        ws = self._ws(('fub', Cc), self.lib.mbx_fuse_bwd_ws, Cc, device=dh.device)
+        self._ck(self.lib.mbx_fuse_bwd(_p(dh), _p(x_st), _p(x_ts), _p(alpha), _p(w), _p(d_st), _p(d_ts), _p(d_st_t), _p(d_ts_t),
+                                       _p(dw), _p(db), M, Cc, _DT[d_st_t.dtype], _p(ws), self._stream()))
+
+    def average(self, x_st, x_ts, out):
+        self._ck(self.lib.mbx_average(_p(x_st), _p(x_ts), _p(out), x_st.numel(), self._stream()))
+
+    def average_bwd(self, dh, d_st, d_ts, d_st_t, d_ts_t):
+        self._ck(self.lib.mbx_average_bwd(_p(dh), _p(d_st), _p(d_ts), _p(d_st_t), _p(d_ts_t), dh.numel(), _DT[d_st_t.dtype],
+                                          self._stream()))
+
+    # ------------------------------------------------------------------ tail
+    def head_fwd(self, rep, w, b, out):
+        M, R = rep.shape
+        self._ck(self.lib.mbx_head_fwd(_p(rep), _p(w), _p(b), _p(out), M, R, w.shape[0], self._stream()))
+
+    def head_bwd(self, dout, rep, w, dpre_t, dw, db):
+        M, R = rep.shape
+        D = w.shape[0]
+        ws = self._ws(('hdb', R, D), self.lib.mbx_head_bwd_ws, R, D, device=rep.device)
+        self._ck(self.lib.mbx_head_bwd(_p(dout), _p(rep), _p(w), _p(dpre_t), _p(dw), _p(db), M, R, D, _DT[dpre_t.dtype], _p(ws),
+                                       self._stream()))
+
+    def tanh_bwd(self, drep, rep, dpre_t):
+        self._ck(self.lib.mbx_tanh_bwd(_p(drep), _p(rep), _p(dpre_t), rep.numel(), _DT[dpre_t.dtype], self._stream()))
+
+
+_OPS: Optional[HipOps] = None
+_OPS_LOCK = threading.Lock()
+
+
+def get() -> HipOps:
+    """Process-wide HipOps instance; raises if libmbx.so is missing (no fallback)."""
+    global _OPS
+    if _OPS is None:
+        with _OPS_LOCK:
+            if _OPS is None:
+                _OPS = HipOps()
+    return _OPS

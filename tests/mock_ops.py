@@ -1,207 +1,2 @@
-"""TEST INFRASTRUCTURE ONLY: a torch (CPU) stand-in for the HIP kernel set.
-
-It implements the `ops` protocol of `motionbert_amd/engine.py` so that the host
-sequencing (which activations are saved, how gradients flow through the dual
-streams, how parameter gradients are laid out) can be verified on a machine
-without a GPU against the reference's autograd gradients.  It is never
-imported by the package and is not a fallback: the product path only knows
-`motionbert_amd.hip_ops.HipOps`.
-
-Each method states the contract the corresponding HIP kernel must satisfy.
-"""
-import math
-
-import torch
-import torch.nn.functional as F
-
-from motionbert_amd.engine import (EPI_DGELU, EPI_GELU, EPI_RESID, EPI_STORE, EPI_TANH, MODE_SPATIAL)
-
-
-def _gelu_grad(u):
-    return 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
-
-
-class MockOps:
-    def __init__(self):
-        self.calls = []
-
-    def _log(self, name):
-        self.calls.append(name)
-
-    # weights -------------------------------------------------------------
-    def prep_weights(self, P, names, tdtype, need_t):
-        self._log('prep_weights')
-        Wn = {n: P[n + '.weight'].detach().to(tdtype).contiguous() for n in names}
-        Wt = {n: P[n + '.weight'].detach().t().to(tdtype).contiguous() for n in names} if need_t else {}
-        return Wn, Wt
-
-    # embedding -----------------------------------------------------------
-    def embed_fwd(self, x, w, b, pos, temp, h, B, T, J):
-        self._log('embed_fwd')
-        y = x.reshape(B, T, J, -1) @ w.t() + b + pos.reshape(1, 1, J, -1) + temp[:, :T]
-        h.copy_(y.reshape(h.shape))
-
-    def embed_bwd(self, dh, x, w, dw, db, dpos, dtemp, dx, B, T, J):
-        self._log('embed_bwd')
-        C = dh.shape[-1]
-        d4 = dh.reshape(B, T, J, C)
-        dw.copy_(dh.t() @ x.reshape(-1, x.shape[-1]))
-        db.copy_(dh.sum(0))
-        dpos.copy_(d4.sum((0, 1)).reshape(dpos.shape))
-        dtemp.zero_()
-        dtemp[0, :T, 0] = d4.sum((0, 2))
-        if dx is not None:
-            dx.copy_((dh @ w).reshape(dx.shape))
-
-    # layernorm -----------------------------------------------------------
-    def layernorm_fwd(self, x, g, b, eps, y_t, mean, rstd):
-        self._log('layernorm_fwd')
-        mu = x.mean(-1)
-        var = ((x - mu[:, None]) ** 2).mean(-1)
-        rs = torch.rsqrt(var + eps)
-        mean.copy_(mu)
-        rstd.copy_(rs)
-        y_t.copy_((((x - mu[:, None]) * rs[:, None]) * g + b).to(y_t.dtype))
-
-    def layernorm_bwd(self, dy_t, x, mean, rstd, g, dres, extra, dx, dx_t, dg, db):
-        """dx = [dres] + [extra] + LN'(dy); dx_t = T copy of dx; dg, db reduced over rows."""
-        self._log('layernorm_bwd')
-        dy = dy_t.float()
-        xhat = (x - mean[:, None]) * rstd[:, None]
-        dg.copy_((dy * xhat).sum(0))
-        db.copy_(dy.sum(0))
-        dxh = dy * g
-        r = rstd[:, None] * (dxh - dxh.mean(-1, keepdim=True) - xhat * (dxh * xhat).mean(-1, keepdim=True))
-        if dres is not None:
-            r = r + dres
-        if extra is not None:
-            r = r + extra
-        dx.copy_(r)
-        if dx_t is not None:
-            dx_t.copy_(r.to(dx_t.dtype))
-
-    # GEMMs ----------------------------------------------------------------
-    def gemm_nt(self, a_t, w_t, bias, epi, out_t=None, out2_t=None, out_f=None, resid=None, aux_t=None):
-        """acc[M,N] = a_t[M,K] @ w_t[N,K]^T in fp32 accumulation, then the epilogue."""
-        self._log(f'gemm_nt.{epi}')
-        acc = a_t.float() @ w_t.float().t()
-        if bias is not None:
-            acc = acc + bias
-        if epi == EPI_STORE:
-            out_t.copy_(acc.to(out_t.dtype))
-        elif epi == EPI_GELU:
-            u = acc.to(out_t.dtype)
-            out_t.copy_(u)
-            out2_t.copy_(F.gelu(acc).to(out2_t.dtype))   # gelu of the fp32 value, as the kernel epilogue does
-        elif epi == EPI_RESID:
-            out_f.copy_(resid + acc)
-        elif epi == EPI_TANH:
-            out_f.copy_(torch.tanh(acc))
-        elif epi == EPI_DGELU:
-            out_t.copy_((acc * _gelu_grad(aux_t.float())).to(out_t.dtype))
-        else:
-            raise ValueError(epi)
-
-    def gemm_tn(self, dy_t, a_t, dw, db):
-        """dw[N,K] = dy_t[M,N]^T @ a_t[M,K]; db[N] = column sums of dy_t (both fp32)."""
-        self._log('gemm_tn')
-        dw.copy_(dy_t.float().t() @ a_t.float())
-        if db is not None:
-            db.copy_(dy_t.float().sum(0))
-
-    # attention -------------------------------------------------------------
-    def _split(self, qkv, B, T, J, H):
-        C = qkv.shape[-1] // 3
-        q5 = qkv.float().reshape(B, T, J, 3, H, C // H)
-        return q5[:, :, :, 0], q5[:, :, :, 1], q5[:, :, :, 2]
-
-    def attn_fwd(self, qkv, o, lse, B, T, J, H, scale, mode):
-        self._log(f'attn_fwd.{mode}')
-        q, k, v = self._split(qkv, B, T, J, H)
-        if mode == MODE_SPATIAL:
-            s = torch.einsum('btihd,btjhd->bthij', q, k) * scale
-            l = torch.logsumexp(s, -1)                      # [B,T,H,J]
-            p = torch.exp(s - l[..., None])
-            oo = torch.einsum('bthij,btjhd->btihd', p, v)
-            lse.copy_(l.permute(0, 1, 3, 2).reshape(lse.shape))
-        else:
-            s = torch.einsum('bsjhd,btjhd->bjhst', q, k) * scale
-            l = torch.logsumexp(s, -1)                      # [B,J,H,T]
-            p = torch.exp(s - l[..., None])
-            oo = torch.einsum('bjhst,btjhd->bsjhd', p, v)
-            lse.copy_(l.permute(0, 3, 1, 2).reshape(lse.shape))
-        o.copy_(oo.reshape(o.shape).to(o.dtype))
-
-    def attn_bwd(self, qkv, o, do, lse, dqkv, B, T, J, H, scale, mode):
-        self._log(f'attn_bwd.{mode}')
-        q, k, v = self._split(qkv, B, T, J, H)
-        hd = q.shape[-1]
-        do5 = do.float().reshape(B, T, J, H, hd)
-        o5 = o.float().reshape(B, T, J, H, hd)
-        delta = (do5 * o5).sum(-1)                           # [B,T,J,H]
-        l4 = lse.reshape(B, T, J, H)
-        out = torch.zeros(B, T, J, 3, H, hd)
-        if mode == MODE_SPATIAL:
-            s = torch.einsum('btihd,btjhd->bthij', q, k) * scale
-            p = torch.exp(s - l4.permute(0, 1, 3, 2)[..., None])
-            dp = torch.einsum('btihd,btjhd->bthij', do5, v)
-            ds = p * (dp - delta.permute(0, 1, 3, 2)[..., None]) * scale
-            out[:, :, :, 0] = torch.einsum('bthij,btjhd->btihd', ds, k)
-            out[:, :, :, 1] = torch.einsum('bthij,btihd->btjhd', ds, q)
-            out[:, :, :, 2] = torch.einsum('bthij,btihd->btjhd', p, do5)
-        else:
-            s = torch.einsum('bsjhd,btjhd->bjhst', q, k) * scale
-            p = torch.exp(s - l4.permute(0, 2, 3, 1)[..., None])
-            dp = torch.einsum('bsjhd,btjhd->bjhst', do5, v)
-            ds = p * (dp - delta.permute(0, 2, 3, 1)[..., None]) * scale
-            out[:, :, :, 0] = torch.einsum('bjhst,btjhd->bsjhd', ds, k)
-            out[:, :, :, 1] = torch.einsum('bjhst,bsjhd->btjhd', ds, q)
-            out[:, :, :, 2] = torch.einsum('bjhst,bsjhd->btjhd', p, do5)
-        dqkv.copy_(out.reshape(dqkv.shape).to(dqkv.dtype))
-
-    # fusion ----------------------------------------------------------------
-    def fuse_fwd(self, x_st, x_ts, w, b, out, alpha):
-        self._log('fuse_fwd')
-        a = torch.softmax(torch.cat([x_st, x_ts], -1) @ w.t() + b, -1)
-        alpha.copy_(a)
-        out.copy_(x_st * a[:, 0:1] + x_ts * a[:, 1:2])
-
-    def fuse_bwd(self, dh, x_st, x_ts, alpha, w, d_st, d_ts, d_st_t, d_ts_t, dw, db):
-        self._log('fuse_bwd')
-        C = x_st.shape[-1]
-        da = torch.stack([(dh * x_st).sum(-1), (dh * x_ts).sum(-1)], -1)
-        dl = alpha * (da - (da * alpha).sum(-1, keepdim=True))
-        dw.copy_(dl.t() @ torch.cat([x_st, x_ts], -1))
-        db.copy_(dl.sum(0))
-        dcat = dl @ w
-        d_st.copy_(dh * alpha[:, 0:1] + dcat[:, :C])
-        d_ts.copy_(dh * alpha[:, 1:2] + dcat[:, C:])
-        d_st_t.copy_(d_st.to(d_st_t.dtype))
-        d_ts_t.copy_(d_ts.to(d_ts_t.dtype))
-
-    def average(self, x_st, x_ts, out):
-        self._log('average')
-        out.copy_((x_st + x_ts) * 0.5)
-
-    def average_bwd(self, dh, d_st, d_ts, d_st_t, d_ts_t):
-        self._log('average_bwd')
-        d_st.copy_(dh * 0.5)
-        d_ts.copy_(dh * 0.5)
-        d_st_t.copy_(d_st.to(d_st_t.dtype))
-        d_ts_t.copy_(d_ts.to(d_ts_t.dtype))
-
-    # tail ------------------------------------------------------------------
-    def head_fwd(self, rep, w, b, out):
-        self._log('head_fwd')
-        out.copy_(rep @ w.t() + b)
-
-    def head_bwd(self, dout, rep, w, dpre_t, dw, db):
-        """dpre = (dout @ w) * (1 - rep^2)  (tanh' folded in);  dw = dout^T rep;  db = sum dout."""
-        self._log('head_bwd')
-        dpre_t.copy_(((dout @ w) * (1 - rep * rep)).to(dpre_t.dtype))
-        dw.copy_(dout.t() @ rep)
-        db.copy_(dout.sum(0))
-
-    def tanh_bwd(self, drep, rep, dpre_t):
-        self._log('tanh_bwd')
-        dpre_t.copy_((drep * (1 - rep * rep)).to(dpre_t.dtype))
+"""Test-side alias of the torch restatement of the kernel set (see oracle/torch_ops.py)."""
+from oracle.torch_ops import MockOps  # noqa: F401

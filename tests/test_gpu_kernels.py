@@ -1,0 +1,265 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry of libmbx.so against a plain PyTorch fp32
+reference of the same op (tests/mock_ops.py, run on the GPU), same seeded inputs.
+
+Tolerances (relative L2 over the whole tensor):
+  fp32 mode  : 2e-5   (exact fp32 MFMA; only the summation order differs)
+  bf16 mode  : fp32 outputs 2e-5 (operands are the same bf16 values, products exact in fp32);
+               bf16 outputs 4e-3 (one rounding of the result); attention 1.5e-2 (P / dS are rounded
+               to bf16 before the second MFMA, as in any bf16 flash attention)
+Every measured error is also appended to gpurun_out/kernel_parity.json for the round report."""
+import json
+import os
+
+import pytest
+import torch
+
+from motionbert_amd.engine import (EPI_DGELU, EPI_GELU, EPI_RESID, EPI_STORE, EPI_TANH, MODE_SPATIAL, MODE_TEMPORAL)
+from tests.mock_ops import MockOps
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+REPORT = {}
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from motionbert_amd import hip_ops
+    return hip_ops.get()
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _dump_report():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'kernel_parity.json'), 'w') as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def check(name, got, ref, tol):
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all(), f'{name}: non-finite output'
+    e = rel(got.float(), ref.float())
+    REPORT[name] = e
+    assert e < tol, f'{name}: rel-l2 {e:.3e} >= {tol:.1e}'
+
+
+def rnd(*shape, seed=0, dtype=torch.float32, scale=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+TD = [torch.float32, torch.bfloat16]
+TOL_T = {torch.float32: 2e-5, torch.bfloat16: 4e-3}
+
+
+def tname(dt):
+    return 'f32' if dt == torch.float32 else 'bf16'
+
+
+# ---------------------------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize('C', [64, 256, 512])
+def test_embed_fwd_bwd(ops, C):
+    B, T, J = 2, 9, 17
+    M = B * T * J
+    x, w, b = rnd(B, T, J, 3, seed=1), rnd(C, 3, seed=2), rnd(C, seed=3)
+    pos, temp = rnd(1, J, C, seed=4), rnd(1, 16, 1, C, seed=5)
+    h, h_ref = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    ops.embed_fwd(x, w, b, pos, temp, h, B, T, J)
+    MockOps().embed_fwd(x, w, b, pos, temp, h_ref, B, T, J)
+    check(f'embed_fwd.C{C}', h, h_ref, 1e-6)
+    dh = rnd(M, C, seed=6)
+    outs = [[torch.full(s, 7.0, device=DEV) for s in [(C, 3), (C,), (1, J, C), (1, 16, 1, C), (B, T, J, 3)]] for _ in range(2)]
+    ops.embed_bwd(dh, x, w, *outs[0], B, T, J)
+    MockOps().embed_bwd(dh, x, w, *outs[1], B, T, J)
+    for n, a, r in zip(['dw', 'db', 'dpos', 'dtemp', 'dx'], *outs):
+        check(f'embed_bwd.{n}.C{C}', a, r, 2e-5)
+
+
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('M,C', [(306, 64), (4131, 256), (4131, 512), (1000, 1024)])
+def test_layernorm(ops, dt, M, C):
+    x, g, b = rnd(M, C, seed=1, scale=2.0) + 0.5, rnd(C, seed=2) * 0.3 + 1, rnd(C, seed=3) * 0.1
+    y, mean, rstd = torch.empty(M, C, device=DEV, dtype=dt), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    y2, mean2, rstd2 = torch.empty_like(y), torch.empty_like(mean), torch.empty_like(rstd)
+    ops.layernorm_fwd(x, g, b, 1e-6, y, mean, rstd)
+    MockOps().layernorm_fwd(x, g, b, 1e-6, y2, mean2, rstd2)
+    tag = f'{tname(dt)}.M{M}.C{C}'
+    check(f'ln_fwd.y.{tag}', y, y2, TOL_T[dt])
+    check(f'ln_fwd.mean.{tag}', mean, mean2, 1e-5)
+    check(f'ln_fwd.rstd.{tag}', rstd, rstd2, 1e-5)
+    dy = rnd(M, C, seed=4, dtype=dt)
+    dres, extra = rnd(M, C, seed=5), rnd(M, C, seed=6)
+    for variant, (dr, ex, want_t) in {'full': (dres, extra, True), 'bare': (None, None, False)}.items():
+        o = [[torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV, dtype=dt) if want_t else None,
+              torch.empty(C, device=DEV), torch.empty(C, device=DEV)] for _ in range(2)]
+        ops.layernorm_bwd(dy, x, mean2, rstd2, g, dr, ex, *o[0])
+        MockOps().layernorm_bwd(dy, x, mean2, rstd2, g, dr, ex, *o[1])
+        check(f'ln_bwd.dx.{variant}.{tag}', o[0][0], o[1][0], 2e-5)
+        if want_t:
+            check(f'ln_bwd.dx_t.{variant}.{tag}', o[0][1], o[1][1], TOL_T[dt])
+        check(f'ln_bwd.dg.{variant}.{tag}', o[0][2], o[1][2], 5e-5)
+        check(f'ln_bwd.db.{variant}.{tag}', o[0][3], o[1][3], 5e-5)
+
+
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('M,C', [(306, 64), (4131, 512)])
+def test_fuse(ops, dt, M, C):
+    x_st, x_ts = rnd(M, C, seed=1), rnd(M, C, seed=2)
+    w, b = rnd(2, 2 * C, seed=3, scale=0.05), rnd(2, seed=4)
+    o = [[torch.empty(M, C, device=DEV), torch.empty(M, 2, device=DEV)] for _ in range(2)]
+    ops.fuse_fwd(x_st, x_ts, w, b, *o[0])
+    MockOps().fuse_fwd(x_st, x_ts, w, b, *o[1])
+    tag = f'{tname(dt)}.M{M}.C{C}'
+    check(f'fuse_fwd.out.{tag}', o[0][0], o[1][0], 1e-5)
+    check(f'fuse_fwd.alpha.{tag}', o[0][1], o[1][1], 1e-5)
+    dh, alpha = rnd(M, C, seed=5), o[1][1]
+    mk = lambda: [torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV, dtype=dt),
+                  torch.empty(M, C, device=DEV, dtype=dt), torch.empty(2, 2 * C, device=DEV), torch.empty(2, device=DEV)]
+    a, r = mk(), mk()
+    ops.fuse_bwd(dh, x_st, x_ts, alpha, w, *a)
+    MockOps().fuse_bwd(dh, x_st, x_ts, alpha, w, *r)
+    for n, u, v, tol in zip(['d_st', 'd_ts', 'd_st_t', 'd_ts_t', 'dw', 'db'], a, r, [2e-5, 2e-5, TOL_T[dt], TOL_T[dt], 5e-5, 5e-5]):
+        check(f'fuse_bwd.{n}.{tag}', u, v, tol)
+    n = M * C
+    avg, avg_r = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    ops.average(x_st, x_ts, avg)
+    MockOps().average(x_st, x_ts, avg_r)
+    check(f'average.{tag}', avg, avg_r, 1e-6)
+    a, r = mk()[:4], mk()[:4]
+    ops.average_bwd(dh, *a)
+    MockOps().average_bwd(dh, *r)
+    for nme, u, v in zip(['d_st', 'd_ts', 'd_st_t', 'd_ts_t'], a, r):
+        check(f'average_bwd.{nme}.{tag}', u, v, TOL_T[dt] if 't' in nme[-2:] else 1e-6)
+
+
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('M,R,D', [(306, 64, 3), (4131, 512, 3), (500, 512, 8)])
+def test_head(ops, dt, M, R, D):
+    rep, w, b = torch.tanh(rnd(M, R, seed=1)), rnd(D, R, seed=2, scale=0.1), rnd(D, seed=3)
+    out, out_r = torch.empty(M, D, device=DEV), torch.empty(M, D, device=DEV)
+    ops.head_fwd(rep, w, b, out)
+    MockOps().head_fwd(rep, w, b, out_r)
+    tag = f'{tname(dt)}.M{M}.R{R}.D{D}'
+    check(f'head_fwd.{tag}', out, out_r, 1e-5)
+    dout = rnd(M, D, seed=4)
+    mk = lambda: [torch.empty(M, R, device=DEV, dtype=dt), torch.empty(D, R, device=DEV), torch.empty(D, device=DEV)]
+    a, r = mk(), mk()
+    ops.head_bwd(dout, rep, w, *a)
+    MockOps().head_bwd(dout, rep, w, *r)
+    for n, u, v, tol in zip(['dpre', 'dw', 'db'], a, r, [TOL_T[dt], 5e-5, 5e-5]):
+        check(f'head_bwd.{n}.{tag}', u, v, tol)
+    drep = rnd(M, R, seed=5)
+    t1, t2 = torch.empty(M, R, device=DEV, dtype=dt), torch.empty(M, R, device=DEV, dtype=dt)
+    ops.tanh_bwd(drep, rep, t1)
+    MockOps().tanh_bwd(drep, rep, t2)
+    check(f'tanh_bwd.{tag}', t1, t2, TOL_T[dt])
+
+
+@pytest.mark.parametrize('dt', TD)
+def test_prep_weights(ops, dt):
+    P = {'a.weight': rnd(192, 64, seed=1), 'b.weight': rnd(64, 128, seed=2), 'c.weight': rnd(1536, 512, seed=3)}
+    Wn, Wt = ops.prep_weights(P, ['a', 'b', 'c'], dt, True)
+    torch.cuda.synchronize()
+    for n in 'abc':
+        w = P[n + '.weight']
+        assert torch.equal(Wn[n], w.to(dt)), n
+        assert torch.equal(Wt[n], w.t().contiguous().to(dt)), n
+    REPORT[f'prep_weights.{tname(dt)}'] = 0.0
+
+
+# ---------------------------------------------------------------------------------------------- GEMMs
+NT_SHAPES = [(306, 64, 64), (306, 192, 64), (306, 64, 192), (306, 128, 64), (4131, 1536, 512), (4131, 512, 512),
+             (4131, 1024, 512), (4131, 512, 1024), (4131, 512, 1536), (1000, 256, 256), (129, 768, 256)]
+
+
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('M,N,K', NT_SHAPES)
+def test_gemm_nt_store(ops, dt, M, N, K):
+    a, w, bias = rnd(M, K, seed=1, dtype=dt), rnd(N, K, seed=2, dtype=dt, scale=0.05), rnd(N, seed=3)
+    out, ref = torch.empty(M, N, device=DEV, dtype=dt), torch.empty(M, N, device=DEV, dtype=dt)
+    ops.gemm_nt(a, w, bias, EPI_STORE, out_t=out)
+    MockOps().gemm_nt(a, w, bias, EPI_STORE, out_t=ref)
+    check(f'gemm_nt.store.{tname(dt)}.{M}x{N}x{K}', out, ref, TOL_T[dt])
+    ops.gemm_nt(a, w, None, EPI_STORE, out_t=out)
+    MockOps().gemm_nt(a, w, None, EPI_STORE, out_t=ref)
+    check(f'gemm_nt.store_nobias.{tname(dt)}.{M}x{N}x{K}', out, ref, TOL_T[dt])
+
+
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('M,N,K', [(306, 128, 64), (4131, 1024, 512), (4131, 512, 1024)])
+def test_gemm_nt_epilogues(ops, dt, M, N, K):
+    a, w, bias = rnd(M, K, seed=1, dtype=dt), rnd(N, K, seed=2, dtype=dt, scale=0.05), rnd(N, seed=3)
+    tag = f'{tname(dt)}.{M}x{N}x{K}'
+    mk_t = lambda: torch.empty(M, N, device=DEV, dtype=dt)
+    mk_f = lambda: torch.empty(M, N, device=DEV)
+    u, g, u2, g2 = mk_t(), mk_t(), mk_t(), mk_t()
+    ops.gemm_nt(a, w, bias, EPI_GELU, out_t=u, out2_t=g)
+    MockOps().gemm_nt(a, w, bias, EPI_GELU, out_t=u2, out2_t=g2)
+    check(f'gemm_nt.gelu.u.{tag}', u, u2, TOL_T[dt])
+    check(f'gemm_nt.gelu.g.{tag}', g, g2, TOL_T[dt])
+    resid = rnd(M, N, seed=4)
+    y, y2 = mk_f(), mk_f()
+    ops.gemm_nt(a, w, bias, EPI_RESID, out_f=y, resid=resid)
+    MockOps().gemm_nt(a, w, bias, EPI_RESID, out_f=y2, resid=resid)
+    check(f'gemm_nt.resid.{tag}', y, y2, 2e-5)
+    ops.gemm_nt(a, w, bias, EPI_TANH, out_f=y)
+    MockOps().gemm_nt(a, w, bias, EPI_TANH, out_f=y2)
+    check(f'gemm_nt.tanh.{tag}', y, y2, 2e-5)
+    aux = rnd(M, N, seed=5, dtype=dt)
+    d, d2 = mk_t(), mk_t()
+    ops.gemm_nt(a, w, None, EPI_DGELU, out_t=d, aux_t=aux)
+    MockOps().gemm_nt(a, w, None, EPI_DGELU, out_t=d2, aux_t=aux)
+    check(f'gemm_nt.dgelu.{tag}', d, d2, TOL_T[dt])
+
+
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('M,N,K', [(306, 64, 64), (306, 192, 64), (306, 64, 128), (4131, 1536, 512), (4131, 512, 1024),
+                                   (4131, 1024, 512), (70227, 512, 512), (33, 64, 64)])
+def test_gemm_tn(ops, dt, M, N, K):
+    dy, a = rnd(M, N, seed=1, dtype=dt), rnd(M, K, seed=2, dtype=dt)
+    dw, db, dw2, db2 = (torch.empty(N, K, device=DEV), torch.empty(N, device=DEV), torch.empty(N, K, device=DEV),
+                        torch.empty(N, device=DEV))
+    ops.gemm_tn(dy, a, dw, db)
+    MockOps().gemm_tn(dy, a, dw2, db2)
+    tag = f'{tname(dt)}.{M}x{N}x{K}'
+    check(f'gemm_tn.dw.{tag}', dw, dw2, 3e-5)
+    check(f'gemm_tn.db.{tag}', db, db2, 3e-5)
+    ops.gemm_tn(dy, a, dw, None)
+    check(f'gemm_tn.dw_nobias.{tag}', dw, dw2, 3e-5)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+ATT = [(2, 9, 2, 32), (2, 9, 8, 64), (3, 30, 8, 32), (2, 81, 8, 32), (2, 81, 8, 64), (1, 243, 8, 64), (1, 243, 8, 32),
+       (2, 100, 2, 64), (1, 1, 8, 64), (5, 33, 8, 64)]
+
+
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('mode', [MODE_SPATIAL, MODE_TEMPORAL])
+@pytest.mark.parametrize('B,T,H,hd', ATT)
+def test_attention(ops, dt, mode, B, T, H, hd):
+    J, C = 17, H * hd
+    M = B * T * J
+    qkv = rnd(M, 3 * C, seed=1, dtype=dt)
+    # make the softmax non-trivial: a few dominant keys (forces large row maxima)
+    qkv[:, :C] *= 2.0
+    scale = hd ** -0.5
+    tol_o = 2e-5 if dt == torch.float32 else 1.5e-2
+    tag = f'{tname(dt)}.{"sp" if mode == MODE_SPATIAL else "tm"}.B{B}T{T}H{H}d{hd}'
+    o, lse = torch.full((M, C), 9.0, device=DEV, dtype=dt), torch.full((M, H), 9.0, device=DEV)
+    o2, lse2 = torch.empty(M, C, device=DEV, dtype=dt), torch.empty(M, H, device=DEV)
+    ops.attn_fwd(qkv, o, lse, B, T, J, H, scale, mode)
+    MockOps().attn_fwd(qkv, o2, lse2, B, T, J, H, scale, mode)
+    check(f'attn_fwd.o.{tag}', o, o2, tol_o)
+    check(f'attn_fwd.lse.{tag}', lse, lse2, 2e-5 if dt == torch.float32 else 1e-4)
+    do = rnd(M, C, seed=2, dtype=dt)
+    dq, dq2 = torch.full((M, 3 * C), 9.0, device=DEV, dtype=dt), torch.empty(M, 3 * C, device=DEV, dtype=dt)
+    ops.attn_bwd(qkv, o2, do, lse2, dq, B, T, J, H, scale, mode)
+    MockOps().attn_bwd(qkv, o2, do, lse2, dq2, B, T, J, H, scale, mode)
+    for i, n in enumerate(['dq', 'dk', 'dv']):
+        check(f'attn_bwd.{n}.{tag}', dq[:, i * C:(i + 1) * C], dq2[:, i * C:(i + 1) * C], 5e-5 if dt == torch.float32 else 2e-2)
