@@ -100,36 +100,71 @@ class TimedOps:
         return agg
 
 
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, p = f.read().split()
+            if q != 'max':
+                n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = max(1, min(n, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(cfg, T, budget_s=20.0):
-    """Torch fp32 port of the hot path on the host cores (oracle/torch_ops.py), fwd+bwd, small batch."""
+    """Torch fp32 port of the hot path on the host cores (oracle/torch_ops.py), fwd+bwd of ONE clip.
+    Bounded: a T=27 probe sizes the sample; if a full-length clip does not fit the budget the probe
+    length is kept and the rate is converted to full-length clips by the FLOP ratio (stated in `sample`)."""
     from motionbert_amd import DSTformer, model as M
     from oracle.torch_ops import MockOps
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = DSTformer(norm_layer=partial(nn.LayerNorm, eps=1e-6), **cfg)
     m.precision = 'fp32'
-    B = 2
-    x, gt = make_batch(B, T, cfg['num_joints'], 1, 'cpu')
 
-    def step():
-        m.zero_grad(set_to_none=True)
-        loss = pose_loss(M.run(MockOps(), m, x), gt)
-        loss.backward()
-    t0 = time.time(); step(); first = time.time() - t0   # warm-up (also sizes the sample)
-    iters = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
-    t0 = time.time()
-    for _ in range(iters):
-        step()
-    dt = (time.time() - t0) / iters
+    def run(Tc, iters):
+        x, gt = make_batch(1, Tc, cfg['num_joints'], 1, 'cpu')
+        t0 = time.time()
+        for _ in range(iters):
+            m.zero_grad(set_to_none=True)
+            pose_loss(M.run(MockOps(), m, x), gt).backward()
+        return (time.time() - t0) / iters
+    run(27, 1)                      # warm-up (thread pool, allocator)
+    t27 = run(27, 1)
+    ratio = model_flops_fwd(cfg, T) / model_flops_fwd(cfg, 27)
+    est_full = t27 * ratio
+    log(f'cpu_baseline: {cores} usable cores, T=27 clip {t27:.2f}s, estimated T={T} clip {est_full:.1f}s')
+    if est_full * 2 <= budget_s:
+        iters = max(1, min(4, int(budget_s / est_full) - 1))
+        run(T, 1)
+        dt = run(T, iters)
+        value, what = 1.0 / dt, f'B=1 T={T}, {iters} timed iter(s) after 1 warm-up'
+    else:
+        iters = max(1, min(8, int(budget_s / max(t27, 1e-3))))
+        dt = run(27, iters)
+        value, what = 1.0 / (dt * ratio), (f'B=1 T=27 x {iters} iter(s) (a T={T} clip would take ~{est_full:.0f}s), '
+                                           f'rate converted to T={T} clips by the matmul-FLOP ratio {ratio:.2f}')
     cpu = 'unknown'
     try:
         with open('/proc/cpuinfo') as f:
             cpu = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
     except Exception:
         pass
-    return dict(value=B / dt, unit='clips/s', cores=cores, kind='port',
-                sample=f'torch fp32 port (oracle/torch_ops.py) of the full model fwd+bwd, B={B} T={T}, {iters} timed iter(s) after 1 warm-up, {cores} threads, CPU: {cpu}')
+    return dict(value=round(value, 4), unit='clips/s', cores=cores, kind='port',
+                sample=f'torch fp32 port (oracle/torch_ops.py) of the full model fwd+bwd, {what}, {cores} threads, CPU: {cpu}')
 
 
 def main():
@@ -179,8 +214,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log(f'rank {rank}/{world}: model on {dev}, B={B} T={T} precision={args.precision}')
+    for i in range(args.warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log(f'first step done, HBM in use {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -193,6 +232,7 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     clips = B * world * args.steps / dt
+    log(f'timed region: {ms:.2f} ms/step, {clips:.1f} clips/s')
 
     # ---- one extra instrumented step (untimed): per-kernel HIP-event durations -> roofline of the dominant kernel
     roof, breakdown = None, None

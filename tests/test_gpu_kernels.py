@@ -36,15 +36,17 @@ def _dump_report():
         json.dump(REPORT, f, indent=1, sort_keys=True)
 
 
-def rel(a, b):
+def rel(a, b, floor=0.0):
     a, b = a.double(), b.double()
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    return float((a - b).norm() / b.norm().clamp_min(max(floor, 1e-30)))
 
 
-def check(name, got, ref, tol):
+def check(name, got, ref, tol, floor=0.0):
+    """relative L2 error; `floor` is an absolute lower bound for the denominator (used where the exact
+    answer is identically zero, e.g. dq/dk of a one-key softmax)."""
     torch.cuda.synchronize()
     assert torch.isfinite(got.float()).all(), f'{name}: non-finite output'
-    e = rel(got.float(), ref.float())
+    e = rel(got.float(), ref.float(), floor)
     REPORT[name] = e
     assert e < tol, f'{name}: rel-l2 {e:.3e} >= {tol:.1e}'
 
@@ -261,5 +263,7 @@ def test_attention(ops, dt, mode, B, T, H, hd):
     dq, dq2 = torch.full((M, 3 * C), 9.0, device=DEV, dtype=dt), torch.empty(M, 3 * C, device=DEV, dtype=dt)
     ops.attn_bwd(qkv, o2, do, lse2, dq, B, T, J, H, scale, mode)
     MockOps().attn_bwd(qkv, o2, do, lse2, dq2, B, T, J, H, scale, mode)
+    # L == 1: p == 1, dS == 0 exactly -> dq = dk = 0; judge those against the scale of dv instead of 0
+    floor = float(dq2[:, 2 * C:].float().norm()) if (T if mode == MODE_TEMPORAL else J) == 1 else 0.0
     for i, n in enumerate(['dq', 'dk', 'dv']):
-        check(f'attn_bwd.{n}.{tag}', dq[:, i * C:(i + 1) * C], dq2[:, i * C:(i + 1) * C], 5e-5 if dt == torch.float32 else 2e-2)
+        check(f'attn_bwd.{n}.{tag}', dq[:, i * C:(i + 1) * C], dq2[:, i * C:(i + 1) * C], 5e-5 if dt == torch.float32 else 2e-2, floor)

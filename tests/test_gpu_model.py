@@ -24,6 +24,21 @@ DEV = 'cuda'
 REPORT = {}
 TOL_FP32 = 1e-3          # the north-star gate
 TOL_BF16_OUT = 4e-2      # bf16 noise floor of the reference under autocast
+TOL_BF16_GRAD = 6e-2     # global relative L2 over all parameter gradients in bf16 mode
+
+
+def grad_errors(got, ref):
+    """(global rel-L2 over all tensors, worst per-tensor error, its name).  A tensor's error is
+    ||got-ref|| / max(||ref||, 1% of the global gradient norm): gradients that are tiny, nearly
+    cancelling sums over tokens (ts_attn.*.bias: d/db0 = -d/db1 = sum of signed per-token terms) are
+    judged against the scale of the whole gradient, not against their own rounding noise."""
+    names = [n for n in ref]
+    g = np.sqrt(sum(float(np.sum(np.asarray(ref[n], np.float64) ** 2)) for n in names))
+    d = np.sqrt(sum(float(np.sum((np.asarray(got[n], np.float64) - np.asarray(ref[n], np.float64)) ** 2)) for n in names))
+    per = {n: float(np.linalg.norm(np.asarray(got[n], np.float64) - np.asarray(ref[n], np.float64)) /
+                    max(np.linalg.norm(np.asarray(ref[n], np.float64)), 0.01 * g)) for n in names}
+    worst = max(per, key=per.get)
+    return d / g, per[worst], worst
 LITE = dict(dim_in=3, dim_out=3, dim_feat=256, dim_rep=512, depth=5, num_heads=8, mlp_ratio=4, num_joints=17, maxlen=243)
 FULL = dict(dim_in=3, dim_out=3, dim_feat=512, dim_rep=512, depth=5, num_heads=8, mlp_ratio=2, num_joints=17, maxlen=243)
 
@@ -62,17 +77,17 @@ def test_tiny_golden_forward_backward(name, precision):
     e_out = rel_l2(out.detach().cpu().numpy(), z['out'])
     (out * torch.from_numpy(z['cot']).to(DEV)).sum().backward()
     e_dx = rel_l2(x.grad.cpu().numpy(), z['dx'])
-    errs = {n: rel_l2(p.grad.cpu().numpy(), z['g.' + n]) for n, p in model.named_parameters() if np.linalg.norm(z['g.' + n]) > 1e-6}
-    worst = max(errs, key=errs.get)
-    REPORT[f'{name}.{precision}'] = dict(out=e_out, dx=e_dx, worst_grad=errs[worst], worst_name=worst)
+    e_all, e_worst, worst = grad_errors({n: p.grad.cpu().numpy() for n, p in model.named_parameters()},
+                                        {n: z['g.' + n] for n, _ in model.named_parameters()})
+    REPORT[f'{name}.{precision}'] = dict(out=e_out, dx=e_dx, grad_global=e_all, worst_grad=e_worst, worst_name=worst)
     rep = model.get_representation(x.detach())
     e_rep = rel_l2(rep.detach().cpu().numpy(), z['rep'])
     if precision == 'fp32':
         assert e_out < TOL_FP32 and e_rep < TOL_FP32 and e_dx < TOL_FP32, (e_out, e_rep, e_dx)
-        assert errs[worst] < TOL_FP32, (worst, errs[worst])
+        assert e_all < TOL_FP32 and e_worst < TOL_FP32, (e_all, worst, e_worst)
     else:
         assert e_out < TOL_BF16_OUT and e_rep < TOL_BF16_OUT, (e_out, e_rep)
-        assert errs[worst] < 0.15, (worst, errs[worst])
+        assert e_all < TOL_BF16_GRAD and e_worst < 0.15, (e_all, worst, e_worst)
 
 
 def test_tiny_golden_representation_path_gradients():
@@ -165,13 +180,13 @@ def test_shape_sweep_fwd_bwd(size, B, T, precision):
     out = model(x)
     (out * cot).sum().backward()
     e_out = rel_l2(out.detach().cpu().numpy(), ref.cpu().numpy())
-    errs = {n: rel_l2(p.grad.cpu().numpy(), gref[n].cpu().numpy()) for n, p in model.named_parameters() if float(gref[n].norm()) > 1e-6}
-    worst = max(errs, key=errs.get)
-    REPORT[f'sweep.{size}.B{B}T{T}.{precision}'] = dict(out=e_out, worst_grad=errs[worst], worst_name=worst)
+    e_all, e_worst, worst = grad_errors({n: p.grad.cpu().numpy() for n, p in model.named_parameters()},
+                                        {n: g.cpu().numpy() for n, g in gref.items()})
+    REPORT[f'sweep.{size}.B{B}T{T}.{precision}'] = dict(out=e_out, grad_global=e_all, worst_grad=e_worst, worst_name=worst)
     if precision == 'fp32':
-        assert e_out < TOL_FP32 and errs[worst] < TOL_FP32, (e_out, worst, errs[worst])
+        assert e_out < TOL_FP32 and e_all < TOL_FP32 and e_worst < TOL_FP32, (e_out, e_all, worst, e_worst)
     else:
-        assert e_out < TOL_BF16_OUT and errs[worst] < 0.25, (e_out, worst, errs[worst])
+        assert e_out < TOL_BF16_OUT and e_all < TOL_BF16_GRAD and e_worst < 0.25, (e_out, e_all, worst, e_worst)
 
 
 def test_infer_wild_call_pattern():
