@@ -16,11 +16,12 @@
 // The score matrix [B,H,J,T,T] that the reference materialises (32 MB per clip) never exists;
 // backward recomputes the probabilities from q, k and the saved log-sum-exp.
 //
-// LDS tiles (per problem):  row-major [KP][hd] tiles padded by 16 B per row (conflict-free 16-byte
-// fragment reads), and for bf16 additionally transposed tiles [hd][KP] (+16 B) built with 8x8
-// register transposes, because an MFMA operand needs its contraction index contiguous per lane.
-// In fp32 mode operands are single floats per lane, so "transposed" reads come straight out of the
-// row-major tile.
+// LDS tiles (per problem): row-major [KP][hd] tiles padded by 16 B per row (conflict-free 16-byte
+// fragment reads).  Products that contract over the SEQUENCE index (P.V, dS^T.Q, ...) need that index
+// contiguous per lane although it is the row index of the tile: bf16 fetches those operands with the
+// gfx950 transpose read ds_read_b64_tr_b16 (lane r of a 16-lane group addresses 4 d-columns of row
+// r >> 2; the hardware hands lane i the 4 consecutive rows of column i), fp32 operands are single floats
+// per lane and are read directly.  No transposed copies exist in LDS.
 // Short sequences (L <= 32: every spatial problem, temporal with T <= 32) run one problem per wave
 // with wave-private LDS, four problems per 256-thread workgroup; longer ones share K/V across the 4
 // waves of a workgroup, which split the 32-row query (key) blocks between them.
@@ -104,19 +105,22 @@ template <int HD> struct MmaRows<float, HD> {
 //   bf16: `tile` is the TRANSPOSED tile [d][e] (e contiguous): two 8-byte reads give the 8 elements of a k-step
 //   fp32: `tile` is the ROW-MAJOR tile [e][d]: scalar reads, consecutive lanes -> consecutive d
 template <typename T> struct MmaCols;
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
 template <> struct MmaCols<bf16_t> {
     static __device__ __forceinline__ void run(const char* tile, int stride, int d0, int f, const f32x16_t& p, int lane,
                                                f32x16_t& acc) {
-        const int g = lane >> 5;
-        const char* row = tile + (size_t)(d0 + (lane & 31)) * stride + (32 * f + 4 * g) * 2;
+        const int g = lane >> 5, r16 = lane & 15;
+        // this lane's address: row base + (r16 >> 2), d-column block d0 + 16*((lane>>4)&1) + 4*(r16&3)
+        const char* a0 = tile + (size_t)(32 * f + 4 * g + (r16 >> 2)) * stride + (d0 + 16 * ((lane >> 4) & 1) + 4 * (r16 & 3)) * 2;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            union { uint32_t u[4]; bf16x8_t v; } pb, a;
+            union { uint32_t u[4]; bf16x8_t v; } pb;
+            union { v4s_t h[2]; bf16x8_t v; } a;
 #pragma unroll
             for (int e = 0; e < 4; ++e) pb.u[e] = pack_bf2(p[8 * t + 2 * e], p[8 * t + 2 * e + 1]);
-            const uint2 lo = *reinterpret_cast<const uint2*>(row + 32 * t);
-            const uint2 hi = *reinterpret_cast<const uint2*>(row + 32 * t + 16);
-            a.u[0] = lo.x; a.u[1] = lo.y; a.u[2] = hi.x; a.u[3] = hi.y;
+            a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(a0 + (size_t)(16 * t) * stride));       // rows base .. base+3
+            a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(a0 + (size_t)(16 * t + 8) * stride));   // rows base+8 .. base+11
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, pb.v, acc, 0, 0, 0);
         }
     }
@@ -148,33 +152,6 @@ __device__ __forceinline__ void fill_rowmajor(char* dst, int stride, const T* sr
         *reinterpret_cast<uint4*>(dst + (size_t)row * stride + ch * 16) = v;
     }
 }
-// transposed (bf16 only): dst[d][row] = src[row][d]
-template <int HD>
-__device__ __forceinline__ void fill_transposed(char* dst, int stride, const bf16_t* src, size_t rstride, int L, int KP,
-                                                int gtid, int gsize) {
-    const int nkb = KP / 8;
-    for (int blk = gtid; blk < nkb * (HD / 8); blk += gsize) {
-        const int kb = blk % nkb, db = blk / nkb;
-        uint32_t rw[32];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (kb * 8 + i < L) v = *reinterpret_cast<const uint4*>(src + (size_t)(kb * 8 + i) * rstride + db * 8);
-            rw[i * 4] = v.x; rw[i * 4 + 1] = v.y; rw[i * 4 + 2] = v.z; rw[i * 4 + 3] = v.w;
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            uint32_t ow[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t lo = rw[(2 * d) * 4 + (c >> 1)], hi = rw[(2 * d + 1) * 4 + (c >> 1)];
-                ow[d] = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
-            }
-            *reinterpret_cast<uint4*>(dst + (size_t)(db * 8 + c) * stride + kb * 16) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        }
-    }
-}
-
 // store an accumulator pair/quad set: lane owns sequence element `row`, registers own d
 template <typename T, int HD>
 __device__ __forceinline__ void store_rowfrag(T* row, const f32x16_t (&acc)[HD / 32], float mul, int g) {
@@ -205,7 +182,6 @@ __device__ __forceinline__ Prob decode_prob(int prob, int mode, int Tn, int J, i
 }
 
 template <typename T> __host__ __device__ constexpr int rm_stride(int HD) { return HD * AT<T>::SZ + 16; }   // row-major tile
-__host__ __device__ constexpr int tr_stride(int KP) { return KP * 2 + 16; }                                  // transposed (bf16)
 
 // ================================================================================================
 // forward: flash-style walk over 32-key fragments with a running row max / row sum (the whole row
@@ -219,9 +195,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
     const int C = H * HD, C3 = 3 * C;
-    const int VSTR = IS_BF ? tr_stride(KP) : KSTR;
+    constexpr int VSTR = KSTR;
     const int KBYTES = KP * KSTR;
-    const int VBYTES = IS_BF ? HD * VSTR : KP * VSTR;
+    const int VBYTES = KP * VSTR;
     int prob = SHARED ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     const bool pvalid = prob < nprob;
     prob = min(prob, nprob - 1);
@@ -232,10 +208,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const size_t rstride = (size_t)P.tstep * C3;
     const T* base = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     fill_rowmajor<T, HD>(kt, KSTR, base + C, rstride, P.L, KP, gtid, gsize);
-    if constexpr (IS_BF)
-        fill_transposed<HD>(vt, VSTR, reinterpret_cast<const bf16_t*>(base + 2 * C), rstride, P.L, KP, gtid, gsize);
-    else
-        fill_rowmajor<T, HD>(vt, VSTR, base + 2 * C, rstride, P.L, KP, gtid, gsize);
+    fill_rowmajor<T, HD>(vt, VSTR, base + 2 * C, rstride, P.L, KP, gtid, gsize);
     __syncthreads();
 
     const int nfr = (P.L + 31) / 32;
@@ -302,8 +275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
     const int C = H * HD, C3 = 3 * C;
-    const int TSTR = tr_stride(KP);
-    const int per_prob = 2 * KP * RSTR + (IS_BF ? HD * TSTR : 0);
+    const int per_prob = 2 * KP * RSTR;
     int prob = SHARED ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     const bool pvalid = prob < nprob;
     prob = min(prob, nprob - 1);
@@ -311,12 +283,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     const int gtid = SHARED ? tid : lane, gsize = SHARED ? 256 : 64;
     char* kt = smem + (SHARED ? 0 : wave * per_prob);
     char* vt = kt + KP * RSTR;
-    char* ktt = vt + KP * RSTR;  // bf16 only: K^T
     const size_t rstride = (size_t)P.tstep * C3;
     const T* base = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     fill_rowmajor<T, HD>(kt, RSTR, base + C, rstride, P.L, KP, gtid, gsize);
     fill_rowmajor<T, HD>(vt, RSTR, base + 2 * C, rstride, P.L, KP, gtid, gsize);
-    if constexpr (IS_BF) fill_transposed<HD>(ktt, TSTR, reinterpret_cast<const bf16_t*>(base + C), rstride, P.L, KP, gtid, gsize);
     __syncthreads();
 
     const int nfr = (P.L + 31) / 32;
@@ -350,7 +320,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
                 s[r] = p * (dp[r] - delta) * scale;  // dS
             }
 #pragma unroll
-            for (int df = 0; df < HD / 32; ++df) MmaCols<T>::run(IS_BF ? ktt : kt, IS_BF ? TSTR : RSTR, df * 32, f, s, lane, dq[df]);
+            for (int df = 0; df < HD / 32; ++df) MmaCols<T>::run(kt, RSTR, df * 32, f, s, lane, dq[df]);
         }
         if (qvalid) store_rowfrag<T, HD>(dqkv + tok * C3 + (size_t)P.h * HD, dq, 1.0f, g);
     }
@@ -369,8 +339,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
     const int C = H * HD, C3 = 3 * C;
-    const int TSTR = tr_stride(KP);
-    const int per_prob = 2 * KP * RSTR + (IS_BF ? 2 * HD * TSTR : 0) + 2 * KP * 4;
+    const int per_prob = 2 * KP * RSTR + 2 * KP * 4;
     int prob = SHARED ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     const bool pvalid = prob < nprob;
     prob = min(prob, nprob - 1);
@@ -378,9 +347,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     const int gtid = SHARED ? tid : lane, gsize = SHARED ? 256 : 64;
     char* qt = smem + (SHARED ? 0 : wave * per_prob);   // Q   [KP][hd]
     char* dot_ = qt + KP * RSTR;                          // dO  [KP][hd]
-    char* qtt = dot_ + KP * RSTR;                         // bf16: Q^T  [hd][KP]
-    char* dott = qtt + (IS_BF ? HD * TSTR : 0);           // bf16: dO^T [hd][KP]
-    float* lse_s = reinterpret_cast<float*>(dott + (IS_BF ? HD * TSTR : 0));
+    float* lse_s = reinterpret_cast<float*>(dot_ + KP * RSTR);
     float* del_s = lse_s + KP;
     const size_t rstride = (size_t)P.tstep * C3, ostride = (size_t)P.tstep * C;
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
@@ -388,10 +355,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
     fill_rowmajor<T, HD>(qt, RSTR, qbase, rstride, P.L, KP, gtid, gsize);
     fill_rowmajor<T, HD>(dot_, RSTR, dobase, ostride, P.L, KP, gtid, gsize);
-    if constexpr (IS_BF) {
-        fill_transposed<HD>(qtt, TSTR, reinterpret_cast<const bf16_t*>(qbase), rstride, P.L, KP, gtid, gsize);
-        fill_transposed<HD>(dott, TSTR, reinterpret_cast<const bf16_t*>(dobase), ostride, P.L, KP, gtid, gsize);
-    }
     // per-query statistics: lse and delta = sum_d dO*O
     for (int q = gtid; q < KP; q += gsize) {
         float l = 0.f, dl = 0.f;
@@ -447,8 +410,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
             }
 #pragma unroll
             for (int df = 0; df < HD / 32; ++df) {
-                MmaCols<T>::run(IS_BF ? dott : dot_, IS_BF ? TSTR : RSTR, df * 32, f, s, lane, dv[df]);   // dV^T += dO^T P
-                MmaCols<T>::run(IS_BF ? qtt : qt, IS_BF ? TSTR : RSTR, df * 32, f, dp, lane, dk[df]);     // dK^T += Q^T dS
+                MmaCols<T>::run(dot_, RSTR, df * 32, f, s, lane, dv[df]);   // dV^T += dO^T P
+                MmaCols<T>::run(qt, RSTR, df * 32, f, dp, lane, dk[df]);    // dK^T += Q^T dS
             }
         }
         if (kvalid) {
@@ -484,7 +447,7 @@ static int set_lds(K kernel, size_t bytes, const char* who) {
 template <typename T, int HD, bool SHARED>
 static int launch_fwd(const void* qkv, void* o, float* lse, int Tn, int J, int H, float scale, int mode, int nprob, int KP, hipStream_t s) {
     constexpr bool IS_BF = sizeof(T) == 2;
-    const size_t per = (size_t)KP * rm_stride<T>(HD) + (IS_BF ? (size_t)HD * tr_stride(KP) : (size_t)KP * rm_stride<T>(HD));
+    const size_t per = (size_t)2 * KP * rm_stride<T>(HD);
     const size_t shm = SHARED ? per : 4 * per;
     auto kern = attn_fwd_kernel<T, HD, SHARED>;
     if (set_lds(kern, shm, "attn_fwd")) return 1;
@@ -515,9 +478,9 @@ template <typename T, int HD, bool SHARED>
 static int launch_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int Tn, int J, int H,
                       float scale, int mode, int nprob, int KP, hipStream_t s) {
     constexpr bool IS_BF = sizeof(T) == 2;
-    const int RSTR = rm_stride<T>(HD), TSTR = tr_stride(KP);
-    const size_t per_dq = (size_t)2 * KP * RSTR + (IS_BF ? HD * TSTR : 0);
-    const size_t per_dkv = (size_t)2 * KP * RSTR + (IS_BF ? 2 * HD * TSTR : 0) + 2 * KP * 4;
+    const int RSTR = rm_stride<T>(HD);
+    const size_t per_dq = (size_t)2 * KP * RSTR;
+    const size_t per_dkv = (size_t)2 * KP * RSTR + 2 * KP * 4;
     const int grid = SHARED ? nprob : (nprob + 3) / 4;
     auto k1 = attn_bwd_dq_kernel<T, HD, SHARED>;
     auto k2 = attn_bwd_dkv_kernel<T, HD, SHARED>;

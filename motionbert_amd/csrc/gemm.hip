@@ -24,6 +24,7 @@
 // and leaves fp32 partial tiles that a deterministic column-sum folds (no atomics); the bias
 // gradient (column sums of dY) rides along in the staging registers.
 #include "mbx_common.h"
+#include <stdlib.h>
 
 template <typename T> struct GemmT;
 template <> struct GemmT<bf16_t> { static constexpr int BK = 64, EPC = 8; };
@@ -250,6 +251,8 @@ extern "C" int mbx_gemm_nt(const void* a, const void* w, const float* bias, int 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MBX_BF16) {
         MBX_CHECK_ARG(K % GemmT<bf16_t>::BK == 0, "gemm_nt(bf16): K=%d must be a multiple of 64", K);
+        if (!mbx_use_v1_gemm())
+            return mbx_launch_gemm_nt_pipe(a, w, bias, epilogue, out_t, out2_t, out_f, resid, aux_t, M, N, K, s);
         return launch_gemm_nt<bf16_t>(a, w, bias, epilogue, out_t, out2_t, out_f, resid, aux_t, M, N, K, s);
     }
     if (dtype == MBX_F32) {
@@ -428,9 +431,15 @@ static int tn_splits(int M, int N, int K, int bms) {
     if (s < 1) s = 1;
     return s;
 }
+bool mbx_use_v1_gemm() {
+    static const bool v1 = [] { const char* e = getenv("MBX_GEMM_V1"); return e && e[0] == '1'; }();
+    return v1;
+}
 extern "C" size_t mbx_gemm_tn_ws(int M, int N, int K) {
     const int s = tn_splits(M, N, K, 32);  // upper bound over both dtypes
-    return ((size_t)s * N * K + (size_t)s * N) * sizeof(float) + 256;
+    const size_t v1 = ((size_t)s * N * K + (size_t)s * N) * sizeof(float) + 256;
+    const size_t v2 = mbx_gemm_tn_pipe_ws(M, N, K);
+    return v1 > v2 ? v1 : v2;
 }
 template <typename T>
 static int launch_gemm_tn(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, void* ws, hipStream_t s) {
@@ -456,7 +465,10 @@ extern "C" int mbx_gemm_tn(const void* dy, const void* a, float* dw, float* db, 
     MBX_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, "gemm_tn: bad shape M=%d N=%d K=%d (N, K %% 8)", M, N, K);
     MBX_CHECK_ARG((size_t)N * K < ((size_t)1 << 31), "gemm_tn: output too large");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MBX_BF16) return launch_gemm_tn<bf16_t>(dy, a, dw, db, M, N, K, ws, s);
+    if (dtype == MBX_BF16) {
+        if (!mbx_use_v1_gemm()) return mbx_launch_gemm_tn_pipe(dy, a, dw, db, M, N, K, ws, s);
+        return launch_gemm_tn<bf16_t>(dy, a, dw, db, M, N, K, ws, s);
+    }
     if (dtype == MBX_F32) return launch_gemm_tn<float>(dy, a, dw, db, M, N, K, ws, s);
     return mbx_set_error("gemm_tn: unknown dtype %d", dtype);
 }

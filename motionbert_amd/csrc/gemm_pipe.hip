@@ -1,0 +1,466 @@
+// Pipelined bf16 MFMA GEMMs for gfx950 (the throughput path; gemm.hip keeps the fp32 parity kernels).
+//
+// Structure (both kernels): 512-thread workgroup = 8 waves (2 per SIMD), one workgroup per CU,
+// a 3-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without touching
+// VGPRs), two k-tiles in flight behind the one being multiplied, ONE raw s_barrier per k-tile and
+// counted s_waitcnt vmcnt(N) (never 0 inside the loop) so that the DMA of tiles t+1, t+2 stays in
+// flight across the barrier while the MFMAs of tile t run.
+//
+//   gemm_nt_pipe : acc[M,N] = A[M,K] . W[N,K]^T, 256 x 128 output tile, wave grid 4(M) x 2(N), each wave
+//                  64 x 64 = 2 x 2 MFMA 32x32x16 tiles; stage = A [256][64] + W [128][64] bf16 = 48 KiB.
+//                  LDS image: rows of 128 B, 16-byte chunk c of row r at physical chunk c ^ ((r >> 1) & 7)
+//                  (conflict-free ds_read_b128 fragment reads).  LDS-DMA writes lane-linear, so the
+//                  swizzle is applied to the per-lane SOURCE address (same involution on both sides).
+//   gemm_tn_pipe : dW[N,K] = dY[M,N]^T . A[M,K] (contraction over the TOKEN dimension, which is the
+//                  slow dimension of both operands).  The tiles are staged untransposed,
+//                  [64 tokens][256 n] and [64 tokens][128 k], and the MFMA fragments are fetched with the
+//                  gfx950 transpose read ds_read_b64_tr_b16: lane r of a 16-lane group supplies the
+//                  address of 4 consecutive elements of token row (r >> 2), column block 4 (r & 3); the
+//                  hardware returns to lane i the 4 consecutive TOKENS of column i (mapping measured on
+//                  hardware with tools/probes/tr_probe.hip).  256 x 128 output tile, split over the
+//                  token dimension, fp32 partial tiles folded by colsum (deterministic, no atomics).
+#include "mbx_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+#define GLDS16(src, dst) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src), (lds_void_t*)(dst), 16, 0, 0)
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below bf16 resolution);
+// erf(u / sqrt 2) and the Gaussian of GELU' share one exponential, exp(-u^2 / 2).
+__device__ __forceinline__ void erf_parts(float u, float& erf_v, float& gauss) {
+    const float x = fabsf(u) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    gauss = __expf(-0.5f * u * u);
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    erf_v = copysignf(fmaf(-poly, gauss, 1.0f), u);
+}
+__device__ __forceinline__ float gelu_fast(float u) {
+    float e, g;
+    erf_parts(u, e, g);
+    return 0.5f * u * (1.0f + e);
+}
+__device__ __forceinline__ float gelu_fast_grad(float u) {
+    float e, g;
+    erf_parts(u, e, g);
+    return fmaf(u * g, 0.39894228040143267794f, 0.5f * (1.0f + e));
+}
+
+__device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
+    const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ================================================================================================
+// gemm_nt_pipe: 256 x 128 tile, BK = 32, 3-stage ring of 24 KiB -> 72 KiB per workgroup, TWO workgroups
+// (16 waves, 4 per SIMD) per CU: while one workgroup drains its tile through the store-bound epilogue
+// the other one keeps the MFMA pipe and the LDS-DMA stream busy.
+// ================================================================================================
+static constexpr int P_BM = 256, P_BN = 128, P_BK = 32, P_ROWB = 64;
+static constexpr int P_A_BYTES = P_BM * P_ROWB, P_W_BYTES = P_BN * P_ROWB, P_STAGE = P_A_BYTES + P_W_BYTES;  // 24 KiB
+static constexpr int P_NSTAGE = 3;
+
+// rows of 64 B = four 16-byte chunks; chunk c of row r at physical chunk c ^ ((r >> 2) & 3)
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * P_ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ out_t,
+                                                              bf16_t* __restrict__ out2_t, float* __restrict__ out_f,
+                                                              const float* __restrict__ resid, const bf16_t* __restrict__ aux,
+                                                              int M, int N, int K, int ntn, int dbg, long long* trace) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 stages x 24 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = xcd_remap2(blockIdx.x, gridDim.x);
+    const int n0 = (lid % ntn) * P_BN, m0 = (lid / ntn) * P_BM;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // LDS-DMA assignment: one instruction = 16 rows x 64 B.  wave w fills A rows [32 w, 32 w + 32) (2 instr)
+    // and W rows [16 w, 16 w + 16) (1 instr).  lane -> (row = R0 + (lane >> 2), physical chunk p = lane & 3),
+    // source chunk = p ^ ((row >> 2) & 3).
+    const int lr = lane >> 2, lp = lane & 3;
+    const bf16_t* srcA[2];
+    const bf16_t* srcW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + lr;
+        srcA[i] = A + (size_t)min(m0 + row, M - 1) * K + ((lp ^ ((row >> 2) & 3)) << 3);
+    }
+    {
+        const int row = wave * 16 + lr;
+        srcW = W + (size_t)min(n0 + row, N - 1) * K + ((lp ^ ((row >> 2) & 3)) << 3);
+    }
+    char* dstA = smem + wave * 32 * P_ROWB;               // + stage * P_STAGE + i * 1024
+    char* dstW = smem + P_A_BYTES + wave * 16 * P_ROWB;   // + stage * P_STAGE
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / P_BK;
+#define NT_ISSUE(kt_, stage_)                                                          \
+    do {                                                                               \
+        const size_t ko_ = (size_t)(kt_) * P_BK;                                       \
+        GLDS16(srcA[0] + ko_, dstA + (stage_) * P_STAGE);                              \
+        GLDS16(srcA[1] + ko_, dstA + (stage_) * P_STAGE + 1024);                       \
+        GLDS16(srcW + ko_, dstW + (stage_) * P_STAGE);                                 \
+    } while (0)
+
+    // dbg bits (diagnostics only, MBX_DBG env): 1 = skip MFMA block, 2 = skip LDS-DMA, 4 = skip epilogue
+    if (!(dbg & 2)) {
+        NT_ISSUE(0, 0);
+        if (nk > 1) NT_ISSUE(1, 1);
+    }
+    const int i = lane & 31, g = lane >> 5;
+    int stage = 0;
+    // diagnostics: cycle stamps of one wave of one workgroup (MBX_TRACE_BUF), 4 per k-tile + 2 for the epilogue
+    const bool tr_on = trace != nullptr && blockIdx.x == 4000 && tid == 0;
+#ifdef MBX_TRACE
+#define TSTAMP(slot_) do { if (tr_on) trace[slot_] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP(slot_) do { (void)tr_on; } while (0)
+#endif
+    TSTAMP(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) WAIT_VMCNT(3); else WAIT_VMCNT(0);   // tile kt landed (this wave's share); kt+1 may fly
+        TSTAMP(1 + kt * 4);
+        __builtin_amdgcn_s_barrier();                          // everyone's share landed; stage (kt+2)%3 is free
+        TSTAMP(2 + kt * 4);
+        if (kt + 2 < nk && !(dbg & 2)) {
+            const int st2 = stage >= 1 ? stage - 1 : 2;        // (kt + 2) % 3
+            NT_ISSUE(kt + 2, st2);
+        }
+        TSTAMP(3 + kt * 4);
+        const char* sA = smem + stage * P_STAGE;
+        const char* sW = sA + P_A_BYTES;
+        if (!(dbg & 1))
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t fw[2], fa[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fw[t] = *reinterpret_cast<const bf16x8_t*>(sW + sw_off(wn * 64 + t * 32 + i, 2 * s + g));
+                fa[t] = *reinterpret_cast<const bf16x8_t*>(sA + sw_off(wm * 64 + t * 32 + i, 2 * s + g));
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+        TSTAMP(4 + kt * 4);
+    }
+#undef NT_ISSUE
+
+    // ---- fused epilogue, coalesced ------------------------------------------------------------------
+    // The accumulator layout (lane = row, 4-column quads) would make every global store touch 32 rows;
+    // each wave transposes its 64 x 64 fp32 tile through LDS (the ring is idle now) in two 64 x 32 halves
+    // and walks each half row-major: one instruction = 8 rows x 32 columns, 16-byte vectors per lane.
+    constexpr int EROW = 32 * 4 + 16;                       // padded LDS row of the per-wave staging half-tile
+    if (dbg & 4) return;
+    __builtin_amdgcn_s_barrier();                           // all waves are done reading the last stage
+    char* er = smem + wave * (64 * EROW);                   // 9 KiB per wave, 72 KiB per workgroup
+    const int ec = (lane & 7) * 4, erow0 = lane >> 3;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(er + (tm * 32 + i) * EROW + (8 * q + 4 * g) * 4) =
+                    make_float4(acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]);
+        const int n = n0 + wn * 64 + tn * 32 + ec;
+        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias && n < N) load4<float>(bias + n, bb);
+#pragma unroll 4
+        for (int p = 0; p < 8; ++p) {
+            const int rl = p * 8 + erow0, m = m0 + wm * 64 + rl;
+            const float4 t4 = *reinterpret_cast<const float4*>(er + rl * EROW + ec * 4);
+            if (m < M && n < N) {
+                float v[4] = {t4.x + bb[0], t4.y + bb[1], t4.z + bb[2], t4.w + bb[3]};
+                const size_t o = (size_t)m * N + n;
+                if (EPI == MBX_EPI_STORE) {
+                    store4<bf16_t>(out_t + o, v);
+                } else if (EPI == MBX_EPI_GELU) {
+                    store4<bf16_t>(out_t + o, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                    store4<bf16_t>(out2_t + o, v);
+                } else if (EPI == MBX_EPI_RESID) {
+                    float r[4];
+                    load4<float>(resid + o, r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r[e];
+                    store4<float>(out_f + o, v);
+                } else if (EPI == MBX_EPI_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                    store4<float>(out_f + o, v);
+                } else if (EPI == MBX_EPI_DGELU) {
+                    float u[4];
+                    load4<bf16_t>(aux + o, u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(u[e]);
+                    store4<bf16_t>(out_t + o, v);
+                }
+            }
+        }
+    }
+    TSTAMP(1 + nk * 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSTAMP(2 + nk * 4);
+#undef TSTAMP
+}
+
+template <typename K>
+static int set_lds_attr(K kernel, size_t bytes, const char* who) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return mbx_set_error("%s: hipFuncSetAttribute(%zu): %s", who, bytes, hipGetErrorString(e));
+    return 0;
+}
+
+int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int epi, void* out_t, void* out2_t, float* out_f,
+                            const float* resid, const void* aux, int M, int N, int K, hipStream_t s) {
+    const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
+    dim3 grid((unsigned)ntn * ntm), block(512);
+    const size_t shm = P_NSTAGE * P_STAGE;
+    static const int dbg = [] { const char* e = getenv("MBX_DBG"); return e ? atoi(e) : 0; }();
+    static long long* const trace = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
+#define MBX_NTP_CASE(E)                                                                                               \
+    case E:                                                                                                           \
+        if (set_lds_attr(gemm_nt_pipe_kernel<E>, shm, "gemm_nt_pipe")) return 1;                                      \
+        hipLaunchKernelGGL((gemm_nt_pipe_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w, bias,   \
+                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn, dbg, trace);          \
+        break;
+    switch (epi) {
+        MBX_NTP_CASE(MBX_EPI_STORE)
+        MBX_NTP_CASE(MBX_EPI_GELU)
+        MBX_NTP_CASE(MBX_EPI_RESID)
+        MBX_NTP_CASE(MBX_EPI_TANH)
+        MBX_NTP_CASE(MBX_EPI_DGELU)
+        default: return mbx_set_error("gemm_nt: unknown epilogue %d", epi);
+    }
+#undef MBX_NTP_CASE
+    MBX_LAUNCH_CHECK("gemm_nt_pipe");
+    return 0;
+}
+
+// ================================================================================================
+// gemm_tn_pipe : dW[N,K] = dY[M,N]^T . A[M,K]
+// ================================================================================================
+// stage: dY tile [64 tokens][256 n] (512 B rows, 32 KiB) + A tile [64 tokens][128 k] (256 B rows, 16 KiB).
+// 64-byte chunk c of token row r sits at physical chunk c ^ (r & 3) (XOR on the low two bits of the
+// chunk index): the four token rows touched by one transpose read then fall into four different
+// 64-byte bank quarters.
+static constexpr int T_BN = 256, T_BK = 128, T_BMS = 64;
+static constexpr int T_Y_BYTES = T_BMS * T_BN * 2, T_A_BYTES = T_BMS * T_BK * 2, T_STAGE = T_Y_BYTES + T_A_BYTES;  // 48 KiB
+
+// byte offset of (token row r, element column c) in a tile with ROWB bytes per row
+template <int ROWB>
+__device__ __forceinline__ int tr_off(int r, int c) {
+    const int byte = c * 2, c64 = byte >> 6;
+    return r * ROWB + (((c64 & ~3) | ((c64 ^ r) & 3)) << 6) + (byte & 63);
+}
+
+// MFMA operand fragment (8 tokens of one column per lane) for columns [col0, col0 + 32) and tokens
+// [tok0 + 8 g, tok0 + 8 g + 8):  two transpose reads of 4 tokens each.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int tok0, int col0, int lane) {
+    const int g = lane >> 5, r16 = lane & 15, nb = col0 + 16 * ((lane >> 4) & 1) + 4 * (r16 & 3);
+    const int t = tok0 + 8 * g + (r16 >> 2);
+    union { v4s_t h[2]; bf16x8_t v; } f;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(tile + tr_off<ROWB>(t, nb)));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(tile + tr_off<ROWB>(t + 4, nb)));
+    return f.v;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A,
+                                                              float* __restrict__ part_w, float* __restrict__ part_b, int M,
+                                                              int N, int K, int ntk, int ntiles, int nsplits,
+                                                              int chunks_per_split, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 stages x 48 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware order: workgroup ids round-robin over the 8 XCDs (private L2s).  XCD x owns the token
+    // splits x, x+8, ... and walks (split, tile) in order, so the ntn*ntk tiles that stream the SAME token
+    // range are resident on one XCD at about the same time and share its L2.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int split = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
+    if (split >= nsplits) return;
+    const int n0 = (tile / ntk) * T_BN, k0 = (tile % ntk) * T_BK;
+    const int wr = wave >> 1, wc = wave & 1;  // wave grid 4 (n) x 2 (k), 64 x 64 each
+    const int nchunks = (M + T_BMS - 1) / T_BMS;
+    const int c_beg = split * chunks_per_split, c_end = min(nchunks, c_beg + chunks_per_split);
+
+    // LDS-DMA: dY tile = 32 instructions of 1 KiB (2 token rows each); A tile = 16 instructions (4 rows each).
+    // wave w: dY rows [8 w, 8 w + 8) (4 instr), A rows [8 w, 8 w + 8) (2 instr).
+    // dY instr i: rows 8w + 2i + (lane >> 5), physical 16-byte chunk p = lane & 31 (row has 32 chunks)
+    // A  instr i: rows 8w + 4i + (lane >> 4), physical chunk p = lane & 15 (row has 16 chunks)
+    // physical chunk p holds logical chunk p ^ ((row & 3) << 2)   [XOR on the 64-byte-chunk bits]
+    int yrow[4], arow[2];
+    size_t ysrc[4], asrc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        yrow[i] = wave * 8 + 2 * i + (lane >> 5);
+        const int p = lane & 31, lc = p ^ ((yrow[i] & 3) << 2);
+        const int col = min(n0 + lc * 8, N - 8);  // columns past N are never stored; clamp keeps the read in bounds
+        ysrc[i] = (size_t)col;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = wave * 8 + 4 * i + (lane >> 4);
+        const int p = lane & 15, lc = p ^ ((arow[i] & 3) << 2);
+        const int col = min(k0 + lc * 8, K - 8);
+        asrc[i] = (size_t)col;
+    }
+    char* dstY = smem + wave * 8 * 512;
+    char* dstA = smem + T_Y_BYTES + wave * 8 * 256;
+
+#define TN_ISSUE(chunk_, stage_)                                                                    \
+    do {                                                                                            \
+        const int mb_ = (chunk_) * T_BMS;                                                           \
+        char* dy_ = dstY + (stage_) * T_STAGE;                                                      \
+        char* da_ = dstA + (stage_) * T_STAGE;                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                            \
+            GLDS16(dY + (size_t)min(mb_ + yrow[i_], M - 1) * N + ysrc[i_], dy_ + i_ * 1024);        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                            \
+            GLDS16(A + (size_t)min(mb_ + arow[i_], M - 1) * K + asrc[i_], da_ + i_ * 1024);         \
+    } while (0)
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // bias gradient = column sums of dY = dY^T . 1: the k-tile-0 workgroups multiply their dY fragments with an
+    // all-ones B operand (one extra MFMA per fragment in the waves of wave-column 0) -- no extra pass over dY.
+    const bool want_db = (part_b != nullptr) && (k0 == 0) && (wc == 0);
+    f32x16_t accb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[a][r] = 0.f;
+    union { uint32_t u[4]; bf16x8_t v; } ones;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;
+
+    const int nc = c_end - c_beg;
+    if (!(dbg & 2)) {
+        if (nc > 0) TN_ISSUE(c_beg, 0);
+        if (nc > 1) TN_ISSUE(c_beg + 1, 1);
+    }
+    int stage = 0;
+    for (int c = 0; c < nc; ++c) {
+        if (c + 1 < nc) WAIT_VMCNT(6); else WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (c + 2 < nc && !(dbg & 2)) {
+            const int st2 = stage >= 1 ? stage - 1 : 2;
+            TN_ISSUE(c_beg + c + 2, st2);
+        }
+        const char* sY = smem + stage * T_STAGE;
+        const char* sA = sY + T_Y_BYTES;
+        // tokens past M in the last chunk: rows were clamped to M-1 (duplicates) -> zero their contribution
+        const int valid = M - (c_beg + c) * T_BMS;   // tokens of this chunk that exist (>= 64 for all but the last)
+        if (!(dbg & 1))
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                // 16 tokens per MFMA k-step
+            bf16x8_t fy[2], fa[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fy[t] = tr_frag<512>(sY, 16 * s, wr * 64 + t * 32, lane);
+                fa[t] = tr_frag<256>(sA, 16 * s, wc * 64 + t * 32, lane);
+            }
+            if (valid < T_BMS) {
+                // lane holds tokens 16 s + 8 g + e (e < 8) in elements e: zero the ones >= valid (one operand suffices)
+                const int tb = 16 * s + 8 * (lane >> 5);
+                union { bf16x8_t v; uint16_t h[8]; } z;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    z.v = fy[t];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (tb + e >= valid) z.h[e] = 0;
+                    fy[t] = z.v;
+                }
+            }
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc)
+                    acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[tr], fa[tc], acc[tr][tc], 0, 0, 0);
+            if (want_db) {
+#pragma unroll
+                for (int tr = 0; tr < 2; ++tr) accb[tr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[tr], ones.v, accb[tr], 0, 0, 0);
+            }
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+#undef TN_ISSUE
+    if (want_db && (lane & 31) == 0) {   // every column of accb holds the same sums: column 0 of each half writes them
+        const int g2 = lane >> 5;
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * g2;
+                if (n < N) part_b[(size_t)split * N + n] = accb[tr][r];
+            }
+    }
+
+    float* pw = part_w + (size_t)split * N * K;
+    const int i = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) {
+            const int k = k0 + wc * 64 + tc * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (k < K && n < N) pw[(size_t)n * K + k] = acc[tr][tc][r];
+            }
+        }
+}
+
+static int tnp_splits(int M, int N, int K) {
+    const int tiles = ((N + T_BN - 1) / T_BN) * ((K + T_BK - 1) / T_BK);
+    const int nchunks = (M + T_BMS - 1) / T_BMS;
+    int s = ((512 / tiles + 7) / 8) * 8;   // ~2 waves of workgroups over the 256 CUs, a multiple of the 8 XCDs
+    if (s > 128) s = 128;
+    if (s > nchunks) s = nchunks;
+    if (s < 1) s = 1;
+    return s;
+}
+size_t mbx_gemm_tn_pipe_ws(int M, int N, int K) {
+    const size_t sp = tnp_splits(M, N, K);
+    return (sp * N * K + sp * N) * sizeof(float) + 256;
+}
+int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, void* ws, hipStream_t s) {
+    const int ntn = (N + T_BN - 1) / T_BN, ntk = (K + T_BK - 1) / T_BK;
+    const int splits = tnp_splits(M, N, K);
+    const int nchunks = (M + T_BMS - 1) / T_BMS;
+    const int cps = (nchunks + splits - 1) / splits;
+    float* part_w = splits == 1 ? dw : (float*)ws;
+    float* part_b = db ? (splits == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
+    const size_t shm = 3 * T_STAGE;
+    static const int dbg = [] { const char* e = getenv("MBX_DBG"); return e ? atoi(e) : 0; }();
+    if (set_lds_attr(gemm_tn_pipe_kernel, shm, "gemm_tn_pipe")) return 1;
+    const int ntiles = ntn * ntk, groups = (splits + 7) / 8;
+    hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(8 * groups * ntiles), dim3(512), shm, s, (const bf16_t*)dy, (const bf16_t*)a, part_w,
+                       part_b, M, N, K, ntk, ntiles, splits, cps, dbg);
+    MBX_LAUNCH_CHECK("gemm_tn_pipe");
+    if (splits > 1) {
+        if (mbx_launch_colsum(part_w, splits, N * K, 0, N * K, dw, s)) return 1;
+        if (db && mbx_launch_colsum(part_b, splits, N, 0, N, db, s)) return 1;
+    }
+    return 0;
+}

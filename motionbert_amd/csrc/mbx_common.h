@@ -28,13 +28,14 @@ int mbx_set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- scalar conversions
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, quiet NaN
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: the compiler lowers these conversions to v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 mbx_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float mbx_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const mbx_f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, mbx_bf16x2_t));
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
@@ -86,3 +87,10 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
 // ---------------------------------------------------------------- column-sum finalize (shared by all reductions)
 // out[c] = sum_{p < nparts} part[p * stride + col0 + c],  c < ncols
 int mbx_launch_colsum(const float* part, int nparts, int stride, int col0, int ncols, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------- pipelined bf16 GEMMs (gemm_pipe.hip)
+int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int epi, void* out_t, void* out2_t, float* out_f,
+                            const float* resid, const void* aux, int M, int N, int K, hipStream_t s);
+size_t mbx_gemm_tn_pipe_ws(int M, int N, int K);
+int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, void* ws, hipStream_t s);
+bool mbx_use_v1_gemm();   // MBX_GEMM_V1=1 selects the simple double-buffered kernels of gemm.hip (A/B testing)
