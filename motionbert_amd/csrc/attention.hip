@@ -140,16 +140,32 @@ template <> struct MmaCols<float> {
 };
 
 // ---- LDS tile fills (cooperative over `gsize` threads, this thread = gtid) -------------------------
-// row-major: dst[row][0..HD) = src[row * rstride + 0..HD)  for row < L, zero for L <= row < KP
+// Two row-major tiles at once: dstX[row][0..HD) = srcX[row * rstrideX + 0..HD) for row < L, zero for
+// L <= row < KP.  All global loads of both tiles are issued before the first LDS store (the rows are
+// kilobytes apart, so each load is a separate HBM/L2 round trip: they must overlap, not serialize).
 template <typename T, int HD>
-__device__ __forceinline__ void fill_rowmajor(char* dst, int stride, const T* src, size_t rstride, int L, int KP, int gtid,
-                                              int gsize) {
-    constexpr int CH = HD / AT<T>::EPC;
-    for (int idx = gtid; idx < KP * CH; idx += gsize) {
-        const int row = idx / CH, ch = idx % CH;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < L) v = *reinterpret_cast<const uint4*>(src + (size_t)row * rstride + ch * AT<T>::EPC);
-        *reinterpret_cast<uint4*>(dst + (size_t)row * stride + ch * 16) = v;
+__device__ __forceinline__ void fill_two(char* dst0, const T* src0, size_t rs0, char* dst1, const T* src1, size_t rs1, int stride,
+                                         int L, int KP, int gtid, int gsize) {
+    constexpr int CH = HD / AT<T>::EPC;   // 16-byte chunks per row; gsize * CH >= KP * CH for both launch shapes
+    constexpr int NPT = CH;               // chunks per thread and tile (KP <= gsize)
+    uint4 v0[NPT], v1[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int idx = gtid + i * gsize, row = idx / CH, ch = idx % CH;
+        v0[i] = make_uint4(0u, 0u, 0u, 0u);
+        v1[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (row < L) {
+            v0[i] = *reinterpret_cast<const uint4*>(src0 + (size_t)row * rs0 + ch * AT<T>::EPC);
+            v1[i] = *reinterpret_cast<const uint4*>(src1 + (size_t)row * rs1 + ch * AT<T>::EPC);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int idx = gtid + i * gsize, row = idx / CH, ch = idx % CH;
+        if (row < KP) {
+            *reinterpret_cast<uint4*>(dst0 + (size_t)row * stride + ch * 16) = v0[i];
+            *reinterpret_cast<uint4*>(dst1 + (size_t)row * stride + ch * 16) = v1[i];
+        }
     }
 }
 // store an accumulator pair/quad set: lane owns sequence element `row`, registers own d
@@ -207,8 +223,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     char* vt = kt + KBYTES;
     const size_t rstride = (size_t)P.tstep * C3;
     const T* base = qkv + P.tok0 * C3 + (size_t)P.h * HD;
-    fill_rowmajor<T, HD>(kt, KSTR, base + C, rstride, P.L, KP, gtid, gsize);
-    fill_rowmajor<T, HD>(vt, VSTR, base + 2 * C, rstride, P.L, KP, gtid, gsize);
+    fill_two<T, HD>(kt, base + C, rstride, vt, base + 2 * C, rstride, KSTR, P.L, KP, gtid, gsize);
     __syncthreads();
 
     const int nfr = (P.L + 31) / 32;
@@ -285,8 +300,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     char* vt = kt + KP * RSTR;
     const size_t rstride = (size_t)P.tstep * C3;
     const T* base = qkv + P.tok0 * C3 + (size_t)P.h * HD;
-    fill_rowmajor<T, HD>(kt, RSTR, base + C, rstride, P.L, KP, gtid, gsize);
-    fill_rowmajor<T, HD>(vt, RSTR, base + 2 * C, rstride, P.L, KP, gtid, gsize);
+    fill_two<T, HD>(kt, base + C, rstride, vt, base + 2 * C, rstride, RSTR, P.L, KP, gtid, gsize);
     __syncthreads();
 
     const int nfr = (P.L + 31) / 32;
@@ -353,25 +367,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     const T* dobase = d_o + P.tok0 * C + (size_t)P.h * HD;
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
-    fill_rowmajor<T, HD>(qt, RSTR, qbase, rstride, P.L, KP, gtid, gsize);
-    fill_rowmajor<T, HD>(dot_, RSTR, dobase, ostride, P.L, KP, gtid, gsize);
-    // per-query statistics: lse and delta = sum_d dO*O
-    for (int q = gtid; q < KP; q += gsize) {
-        float l = 0.f, dl = 0.f;
-        if (q < P.L) {
-            l = lse[(P.tok0 + (size_t)q * P.tstep) * H + P.h];
-            const T* a = dobase + (size_t)q * ostride;
-            const T* b = obase + (size_t)q * ostride;
+    fill_two<T, HD>(qt, qbase, rstride, dot_, dobase, ostride, RSTR, P.L, KP, gtid, gsize);
+    // per-query statistics: lse and delta = sum_d dO*O.  KP <= gsize: one row per thread, all 2*HD/4 (8) vector
+    // loads of the row in flight together.
+    {
+        const int q = gtid;
+        if (q < KP) {
+            float l = 0.f, dl = 0.f;
+            if (q < P.L) {
+                l = lse[(P.tok0 + (size_t)q * P.tstep) * H + P.h];
+                const T* a = dobase + (size_t)q * ostride;
+                const T* b = obase + (size_t)q * ostride;
+                float x[HD / 4][4], y[HD / 4][4];
 #pragma unroll
-            for (int d = 0; d < HD; d += 4) {
-                float x[4], y[4];
-                load4<T>(a + d, x);
-                load4<T>(b + d, y);
-                dl = fmaf(x[0], y[0], fmaf(x[1], y[1], fmaf(x[2], y[2], fmaf(x[3], y[3], dl))));
+                for (int d = 0; d < HD / 4; ++d) { load4<T>(a + 4 * d, x[d]); load4<T>(b + 4 * d, y[d]); }
+#pragma unroll
+                for (int d = 0; d < HD / 4; ++d)
+                    dl = fmaf(x[d][0], y[d][0], fmaf(x[d][1], y[d][1], fmaf(x[d][2], y[d][2], fmaf(x[d][3], y[d][3], dl))));
             }
+            lse_s[q] = l;
+            del_s[q] = dl;
         }
-        lse_s[q] = l;
-        del_s[q] = dl;
     }
     __syncthreads();
 

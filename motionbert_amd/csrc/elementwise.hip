@@ -302,7 +302,7 @@ __device__ __forceinline__ void block_fold_store(const float* lds /*[4][n]*/, in
 // LayerNorm backward (+ residual-gradient add, + T copy for the next GEMM)
 // partial row layout: [dgamma C | dbeta C]
 // ------------------------------------------------------------------------------------------------
-#define LN_BWD_BLOCKS 512
+#define LN_BWD_BLOCKS 2048
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -459,7 +459,7 @@ extern "C" int mbx_fuse_fwd(const float* x_st, const float* x_ts, const float* w
 // ------------------------------------------------------------------------------------------------
 // adaptive fusion backward.  partial row layout: [dw 4C | db 2 | pad 2]
 // ------------------------------------------------------------------------------------------------
-#define FUSE_BWD_BLOCKS 512
+#define FUSE_BWD_BLOCKS 2048
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void fuse_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x_st,
                                                        const float* __restrict__ x_ts, const float* __restrict__ alpha,
@@ -647,7 +647,7 @@ extern "C" int mbx_head_fwd(const float* rep, const float* w, const float* b, fl
 }
 
 // head backward: dpre = (dout . w) * (1 - rep^2); partial row layout: [dw Dout*R | db 8]
-#define HEAD_BWD_BLOCKS 512
+#define HEAD_BWD_BLOCKS 1024
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ rep,
                                                        const float* __restrict__ w, T* __restrict__ dpre,
