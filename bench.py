@@ -197,7 +197,9 @@ def main():
     model.precision = args.precision
     net = model
     if world > 1:
-        net = nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=64, gradient_as_bucket_view=True)
+        # one replica per GPU; gradient buckets are all-reduced over RCCL while backward is still running
+        from motionbert_amd.ddp import DistributedDSTformer
+        net = DistributedDSTformer(model)
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0.01, fused=True)
     B, T, J = args.batch, args.frames, FULL['num_joints']
     x, gt = make_batch(B, T, J, 100 + rank, dev)

@@ -84,6 +84,16 @@ def linear_names(cfg: ModelCfg) -> List[str]:
     return names
 
 
+def grad_bucket(name: str, depth: int) -> int:
+    """Bucket of a parameter in backward completion order: tail first, then the levels from the
+    last to the first, the embedding last.  The flat gradient buffer is laid out bucket by bucket."""
+    if name.startswith(('head.', 'pre_logits.', 'norm.')):
+        return 0
+    if name.startswith(('blocks_st.', 'blocks_ts.', 'ts_attn.')):
+        return depth - int(name.split('.')[1])
+    return depth + 1
+
+
 class Engine:
     """One forward (and optionally backward) pass.  `P` maps reference state_dict
     names to fp32 device tensors; `Wn[name]` / `Wt[name]` are the T-typed [N,K]
@@ -179,9 +189,12 @@ class Engine:
         return y, sv
 
     # ----------------------------------------------------------------- backward
-    def backward(self, saved, dout: torch.Tensor, grads: Dict[str, torch.Tensor], want_dx: bool):
+    def backward(self, saved, dout: torch.Tensor, grads: Dict[str, torch.Tensor], want_dx: bool, on_ready=None):
         """Fills `grads[name]` (fp32, pre-allocated, same shapes as the parameters) and
-        returns d(input) or None.  `dout` is d(out) with the shape `forward` returned."""
+        returns d(input) or None.  `dout` is d(out) with the shape `forward` returned.
+        `on_ready(bucket)` is called as soon as every gradient of a bucket has been enqueued
+        (bucket 0 = tail, 1..depth = levels depth-1..0, depth+1 = embedding; see `grad_bucket`):
+        the data-parallel wrapper starts that bucket's all-reduce while backward continues."""
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C, R = self.M, cfg.C, cfg.R
         B, T, J = self.B, self.Tlen, cfg.J
@@ -202,6 +215,8 @@ class Engine:
         ops.layernorm_bwd(dxn, saved['h'], saved['mean'], saved['rstd'], P['norm.weight'],
                           None, None, dh, None, G['norm.weight'], G['norm.bias'])
         del dxn, dpre
+        if on_ready is not None:
+            on_ready(0)
         for i in reversed(range(cfg.depth)):
             lv = saved['levels'][i]
             d_st, d_ts = self._f(M, C), self._f(M, C)
@@ -217,9 +232,13 @@ class Engine:
             dh, _ = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', d1, last_needs_t=False)
             del d_ts, d_ts_t, d1
             saved['levels'][i] = None  # release this level's activations
+            if on_ready is not None:
+                on_ready(cfg.depth - i)
         dx = torch.empty_like(saved['x']) if want_dx else None
         ops.embed_bwd(dh, saved['x'], P['joints_embed.weight'], G['joints_embed.weight'], G['joints_embed.bias'],
                       G['pos_embed'], G['temp_embed'], dx, B, T, J)
+        if on_ready is not None:
+            on_ready(cfg.depth + 1)
         return dx
 
     def _block_bwd(self, dy, dy_t, svs, pre, kind, extra_last, last_needs_t):

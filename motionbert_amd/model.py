@@ -28,7 +28,7 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
-from .engine import Engine, ModelCfg
+from .engine import Engine, ModelCfg, grad_bucket
 
 _DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32}
 
@@ -109,13 +109,13 @@ class _DSTformerFn(torch.autograd.Function):
     fixed sequence of HIP kernel launches on the current stream."""
 
     @staticmethod
-    def forward(ctx, ops, cfg, names, tdtype, return_rep, x, *params):
-        need_grad = any(ctx.needs_input_grad[5:])
+    def forward(ctx, ops, cfg, names, tdtype, return_rep, grad_sync, x, *params):
+        need_grad = any(ctx.needs_input_grad[6:])
         P = dict(zip(names, params))
         eng = Engine(ops, cfg, P, tdtype)
         out, saved = eng.forward(x, return_rep, need_grad)
         if need_grad:
-            ctx.eng, ctx.saved_acts, ctx.names = eng, saved, names
+            ctx.eng, ctx.saved_acts, ctx.names, ctx.grad_sync = eng, saved, names, grad_sync
             ctx.pshapes = [p.shape for p in params]
         return out
 
@@ -126,18 +126,30 @@ class _DSTformerFn(torch.autograd.Function):
         if saved is None:
             raise RuntimeError('DSTformer backward called twice (activations were released)')
         dout = dout.contiguous().float()
+        # one flat fp32 gradient buffer, laid out in backward completion order (bucket by bucket) so that a
+        # data-parallel wrapper can all-reduce each bucket as one contiguous RCCL call while backward runs on
+        depth = eng.cfg.depth
+        order = sorted(range(len(names)), key=lambda i: (grad_bucket(names[i], depth), i))
         sizes = [int(torch.Size(s).numel()) for s in ctx.pshapes]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dout.device)
         grads: Dict[str, torch.Tensor] = {}
+        bounds = [0] * (depth + 3)
         off = 0
-        for n, s, sz in zip(names, ctx.pshapes, sizes):
-            grads[n] = flat[off:off + sz].view(s)
-            off += sz
-        dx = eng.backward(saved, dout, grads, want_dx=ctx.needs_input_grad[5])
+        for i in order:
+            grads[names[i]] = flat[off:off + sizes[i]].view(ctx.pshapes[i])
+            off += sizes[i]
+            bounds[grad_bucket(names[i], depth) + 1] = off
+        for b in range(1, len(bounds)):          # empty buckets (e.g. no ts_attn) inherit the running offset
+            bounds[b] = max(bounds[b], bounds[b - 1])
+        sync = ctx.grad_sync
+        on_ready = (lambda b: sync.bucket_ready(flat[bounds[b]:bounds[b + 1]])) if sync is not None else None
+        dx = eng.backward(saved, dout, grads, want_dx=ctx.needs_input_grad[6], on_ready=on_ready)
+        if sync is not None:
+            sync.finish()
         ctx.saved_acts = None
         ctx.eng = None
-        gp = tuple(grads[n] if ng else None for n, ng in zip(names, ctx.needs_input_grad[6:]))
-        return (None, None, None, None, None, dx) + gp
+        gp = tuple(grads[n] if ng else None for n, ng in zip(names, ctx.needs_input_grad[7:]))
+        return (None, None, None, None, None, None, dx) + gp
 
 
 def make_cfg(model) -> ModelCfg:
@@ -147,11 +159,12 @@ def make_cfg(model) -> ModelCfg:
                     att_fuse=model.att_fuse, qkv_bias=model.qkv_bias)
 
 
-def run(ops, model, x, return_rep=False):
-    """Run the fused path of `model` on `x` with an explicit kernel provider."""
+def run(ops, model, x, return_rep=False, grad_sync=None):
+    """Run the fused path of `model` on `x` with an explicit kernel provider.  `grad_sync` (optional) is
+    told about finished gradient buckets during backward (see motionbert_amd.ddp)."""
     cfg = make_cfg(model)
     names, params = zip(*model.named_parameters())
-    return _DSTformerFn.apply(ops, cfg, names, _DTYPES[model.precision], return_rep, x, *params)
+    return _DSTformerFn.apply(ops, cfg, names, _DTYPES[model.precision], return_rep, grad_sync, x, *params)
 
 
 class DSTformer(nn.Module):
@@ -239,7 +252,7 @@ class DSTformer(nn.Module):
         self._check(x)
         from . import hip_ops
         x = x.contiguous().float()
-        return run(hip_ops.get(), self, x, return_rep)
+        return run(hip_ops.get(), self, x, return_rep, getattr(self, '_grad_sync', None))
 
     def get_representation(self, x):
         return self.forward(x, return_rep=True)
