@@ -176,19 +176,24 @@ def main():
     ap.add_argument('--frames', type=int, default=243)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' only for wiring tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a ROCm device (the hot path has no CPU implementation)'
+    local = local % torch.cuda.device_count()   # (wiring tests may oversubscribe one GPU with the gloo backend)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)   # RCCL over xGMI
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
 
     from motionbert_amd import DSTformer, hip_ops, model as M
