@@ -28,6 +28,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
 
+import os
+
 import torch
 
 # GEMM epilogues (values mirror enum mbx_epilogue in include/mbx.h)
@@ -99,10 +101,55 @@ class Engine:
     names to fp32 device tensors; `Wn[name]` / `Wt[name]` are the T-typed [N,K]
     and transposed [K,N] copies produced by ops.prep_weights."""
 
+    _side_streams: Dict[int, Any] = {}
+
     def __init__(self, ops, cfg: ModelCfg, P: Dict[str, torch.Tensor], tdtype: torch.dtype):
         self.ops, self.cfg, self.P, self.T = ops, cfg, P, tdtype
         self.Wn: Dict[str, torch.Tensor] = {}
         self.Wt: Dict[str, torch.Tensor] = {}
+        # The st and ts blocks of a level are independent (DSTformer.py:341-342 feeds both the same x): with
+        # MBX_DUAL_STREAM=1 the ts block runs on a second HIP stream so that HBM-bound kernels of one stream
+        # (LayerNorm, GEMM epilogues) overlap MFMA-bound kernels of the other.
+        self.dual = os.environ.get('MBX_DUAL_STREAM', '1') == '1'
+        # weight-gradient GEMMs feed nothing downstream in backward: MBX_WGRAD_STREAM=1 issues them on a third stream
+        self.wgrad_async = os.environ.get('MBX_WGRAD_STREAM', '0') == '1'
+
+    def _streams(self):
+        """(main, side) streams for the dual-stream schedule, or (None, None)."""
+        if not (self.dual and self.dev.type == 'cuda'):
+            return None, None
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        side = Engine._side_streams.get(idx)
+        if side is None:
+            side = Engine._side_streams[idx] = torch.cuda.Stream(device=idx)
+        return torch.cuda.current_stream(idx), side
+
+    _w_streams: Dict[int, Any] = {}
+
+    def _wstream(self):
+        if not (self.wgrad_async and self.dev.type == 'cuda'):
+            return None
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        ws = Engine._w_streams.get(idx)
+        if ws is None:
+            ws = Engine._w_streams[idx] = torch.cuda.Stream(device=idx)
+        return ws
+
+    def _tn(self, dy_t, a_t, dw, db):
+        """dW / db GEMM, optionally on the weight-gradient stream (call it BEFORE the dX GEMM of the same dy)."""
+        ws = self._wstream()
+        if ws is None:
+            return self.ops.gemm_tn(dy_t, a_t, dw, db)
+        ws.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ws):
+            self.ops.gemm_tn(dy_t, a_t, dw, db)
+        dy_t.record_stream(ws)
+        a_t.record_stream(ws)
+
+    def _join_wgrads(self):
+        ws = self._wstream()
+        if ws is not None:
+            torch.cuda.current_stream().wait_stream(ws)
 
     # ------------------------------------------------------------------ helpers
     def _f(self, *shape):
@@ -125,9 +172,17 @@ class Engine:
         h = self._f(M, C)
         ops.embed_fwd(x, P['joints_embed.weight'], P['joints_embed.bias'], P['pos_embed'], P['temp_embed'], h, B, T, J)
         saved: Dict[str, Any] = dict(x=x, levels=[], return_rep=return_rep)
+        main, side = self._streams()
         for i in range(cfg.depth):
-            x_st, sv_st = self._block_fwd(h, f'blocks_st.{i}', 'st', need_grad)
-            x_ts, sv_ts = self._block_fwd(h, f'blocks_ts.{i}', 'ts', need_grad)
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    x_ts, sv_ts = self._block_fwd(h, f'blocks_ts.{i}', 'ts', need_grad)
+                x_st, sv_st = self._block_fwd(h, f'blocks_st.{i}', 'st', need_grad)
+                main.wait_stream(side)
+            else:
+                x_st, sv_st = self._block_fwd(h, f'blocks_st.{i}', 'st', need_grad)
+                x_ts, sv_ts = self._block_fwd(h, f'blocks_ts.{i}', 'ts', need_grad)
             hn = self._f(M, C)
             if cfg.att_fuse:
                 alpha = self._f(M, 2)
@@ -209,13 +264,14 @@ class Engine:
             ops.head_bwd(dout.reshape(M, cfg.dim_out), saved['rep'], P['head.weight'], dpre,
                          G['head.weight'], G['head.bias'])
         dxn = self._t(M, C)
+        self._tn(dpre, saved['xn'], G['pre_logits.fc.weight'], G['pre_logits.fc.bias'])
         ops.gemm_nt(dpre, self.Wt['pre_logits.fc'], None, EPI_STORE, out_t=dxn)
-        ops.gemm_tn(dpre, saved['xn'], G['pre_logits.fc.weight'], G['pre_logits.fc.bias'])
         dh = self._f(M, C)
         ops.layernorm_bwd(dxn, saved['h'], saved['mean'], saved['rstd'], P['norm.weight'],
                           None, None, dh, None, G['norm.weight'], G['norm.bias'])
         del dxn, dpre
         if on_ready is not None:
+            self._join_wgrads()
             on_ready(0)
         for i in reversed(range(cfg.depth)):
             lv = saved['levels'][i]
@@ -226,17 +282,28 @@ class Engine:
                              d_st, d_ts, d_st_t, d_ts_t, G[f'ts_attn.{i}.weight'], G[f'ts_attn.{i}.bias'])
             else:
                 ops.average_bwd(dh, d_st, d_ts, d_st_t, d_ts_t)
-            d1, _ = self._block_bwd(d_st, d_st_t, lv['st'], f'blocks_st.{i}', 'st', None, last_needs_t=False)
-            del d_st, d_st_t
-            # the second stream's last LN-backward also adds the first stream's input gradient
-            dh, _ = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', d1, last_needs_t=False)
-            del d_ts, d_ts_t, d1
+            main, side = self._streams()
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    d2, _ = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', None, last_needs_t=False)
+                d1, _ = self._block_bwd(d_st, d_st_t, lv['st'], f'blocks_st.{i}', 'st', None, last_needs_t=False)
+                main.wait_stream(side)
+                dh = d1.add_(d2)
+                del d2
+            else:
+                d1, _ = self._block_bwd(d_st, d_st_t, lv['st'], f'blocks_st.{i}', 'st', None, last_needs_t=False)
+                # the second stream's last LN-backward also adds the first stream's input gradient
+                dh, _ = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', d1, last_needs_t=False)
+            del d_st, d_st_t, d_ts, d_ts_t, d1
             saved['levels'][i] = None  # release this level's activations
             if on_ready is not None:
+                self._join_wgrads()
                 on_ready(cfg.depth - i)
         dx = torch.empty_like(saved['x']) if want_dx else None
         ops.embed_bwd(dh, saved['x'], P['joints_embed.weight'], G['joints_embed.weight'], G['joints_embed.bias'],
                       G['pos_embed'], G['temp_embed'], dx, B, T, J)
+        self._join_wgrads()
         if on_ready is not None:
             on_ready(cfg.depth + 1)
         return dx
@@ -258,14 +325,14 @@ class Engine:
         cfg, ops, P, G = self.cfg, self.ops, self.P, self.grads
         M, C = self.M, cfg.C
         do = self._t(M, C)
+        self._tn(dy_t, sv['o'], G[f'{pre}.{attn}.proj.weight'], G[f'{pre}.{attn}.proj.bias'])
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{attn}.proj'], None, EPI_STORE, out_t=do)
-        ops.gemm_tn(dy_t, sv['o'], G[f'{pre}.{attn}.proj.weight'], G[f'{pre}.{attn}.proj.bias'])
         dqkv = self._t(M, 3 * C)
         ops.attn_bwd(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
         del do
         dxn = self._t(M, C)
+        self._tn(dqkv, sv['xn'], G[f'{pre}.{attn}.qkv.weight'], G.get(f'{pre}.{attn}.qkv.bias'))
         ops.gemm_nt(dqkv, self.Wt[f'{pre}.{attn}.qkv'], None, EPI_STORE, out_t=dxn)
-        ops.gemm_tn(dqkv, sv['xn'], G[f'{pre}.{attn}.qkv.weight'], G.get(f'{pre}.{attn}.qkv.bias'))
         del dqkv
         dx = self._f(M, C)
         dx_t = self._t(M, C) if need_t else None
@@ -277,11 +344,11 @@ class Engine:
         cfg, ops, P, G = self.cfg, self.ops, self.P, self.grads
         M, C = self.M, cfg.C
         du = self._t(M, cfg.hidden)
+        self._tn(dy_t, sv['g'], G[f'{pre}.{mlp}.fc2.weight'], G[f'{pre}.{mlp}.fc2.bias'])
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], None, EPI_DGELU, out_t=du, aux_t=sv['u'])
-        ops.gemm_tn(dy_t, sv['g'], G[f'{pre}.{mlp}.fc2.weight'], G[f'{pre}.{mlp}.fc2.bias'])
         dxn = self._t(M, C)
+        self._tn(du, sv['xn'], G[f'{pre}.{mlp}.fc1.weight'], G[f'{pre}.{mlp}.fc1.bias'])
         ops.gemm_nt(du, self.Wt[f'{pre}.{mlp}.fc1'], None, EPI_STORE, out_t=dxn)
-        ops.gemm_tn(du, sv['xn'], G[f'{pre}.{mlp}.fc1.weight'], G[f'{pre}.{mlp}.fc1.bias'])
         del du
         dx = self._f(M, C)
         dx_t = self._t(M, C) if need_t else None
