@@ -219,6 +219,141 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
 #undef TSTAMP
 }
 
+// ================================================================================================
+// gemm_nt_pipe256: 256 x 256 tile, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 MFMA tiles
+// (6 LDS fragment reads per 8 MFMAs instead of 4 per 4), BK = 32, 4-stage ring of 32 KiB (three k-tiles
+// in flight), one workgroup per CU.  Versus the 256 x 128 kernel it moves 1/3 fewer bytes L2 -> LDS and
+// 1/4 fewer bytes LDS -> registers per FLOP; both paths showed up as the limiters of that kernel's loop.
+// ================================================================================================
+static constexpr int Q_BM = 256, Q_BN = 256, Q_BK = 32;
+static constexpr int Q_A_BYTES = Q_BM * P_ROWB, Q_W_BYTES = Q_BN * P_ROWB, Q_STAGE = Q_A_BYTES + Q_W_BYTES;  // 32 KiB
+static constexpr int Q_NSTAGE = 4;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pipe256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                 const float* __restrict__ bias, bf16_t* __restrict__ out_t,
+                                                                 bf16_t* __restrict__ out2_t, float* __restrict__ out_f,
+                                                                 const float* __restrict__ resid, const bf16_t* __restrict__ aux,
+                                                                 int M, int N, int K, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 stages x 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = xcd_remap2(blockIdx.x, gridDim.x);
+    const int n0 = (lid % ntn) * Q_BN, m0 = (lid / ntn) * Q_BM;
+    const int wm = wave >> 2, wn = wave & 3;   // wave tile: rows [128 wm, +128), cols [64 wn, +64)
+
+    // LDS-DMA: one instruction = 16 rows x 64 B; wave w fills rows [32 w, 32 w + 32) of A and of W (2 + 2 instr)
+    const int lr = lane >> 2, lp = lane & 3;
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + lr;
+        const int sw = (lp ^ ((row >> 2) & 3)) << 3;
+        srcA[i] = A + (size_t)min(m0 + row, M - 1) * K + sw;
+        srcW[i] = W + (size_t)min(n0 + row, N - 1) * K + sw;
+    }
+    char* dstA = smem + wave * 32 * P_ROWB;
+    char* dstW = smem + Q_A_BYTES + wave * 32 * P_ROWB;
+
+    f32x16_t acc[2][4];   // [tn][tm]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / Q_BK;
+#define Q_ISSUE(kt_, stage_)                                                           \
+    do {                                                                               \
+        const size_t ko_ = (size_t)(kt_) * Q_BK;                                       \
+        GLDS16(srcA[0] + ko_, dstA + (stage_) * Q_STAGE);                              \
+        GLDS16(srcA[1] + ko_, dstA + (stage_) * Q_STAGE + 1024);                       \
+        GLDS16(srcW[0] + ko_, dstW + (stage_) * Q_STAGE);                              \
+        GLDS16(srcW[1] + ko_, dstW + (stage_) * Q_STAGE + 1024);                       \
+    } while (0)
+
+    Q_ISSUE(0, 0);
+    if (nk > 1) Q_ISSUE(1, 1);
+    if (nk > 2) Q_ISSUE(2, 2);
+    const int i = lane & 31, g = lane >> 5;
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = nk - 1 - kt;                 // tiles issued after kt that may stay in flight (<= 2)
+        if (ahead >= 2) WAIT_VMCNT(8); else if (ahead == 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();                  // tile kt landed for everyone; stage (kt+3)%4 is free
+        if (kt + 3 < nk) Q_ISSUE(kt + 3, (stage + 3) & 3);
+        const char* sA = smem + stage * Q_STAGE;
+        const char* sW = sA + Q_A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t fw[2], fa[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fw[t] = *reinterpret_cast<const bf16x8_t*>(sW + sw_off(wn * 64 + t * 32 + i, 2 * s + g));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const bf16x8_t*>(sA + sw_off(wm * 128 + t * 32 + i, 2 * s + g));
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+        }
+        stage = (stage + 1) & 3;
+    }
+#undef Q_ISSUE
+
+    // coalesced epilogue: four passes of a 32-row x 64-column staging tile per wave (8.5 KiB, 68 KiB per workgroup)
+    constexpr int EROW = 64 * 4 + 16;
+    __builtin_amdgcn_s_barrier();
+    char* er = smem + wave * (32 * EROW);
+    const int ec = (lane & 15) * 4, erow0 = lane >> 4;
+    const int n = n0 + wn * 64 + ec;
+    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias && n < N) load4<float>(bias + n, bb);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(er + i * EROW + (tn * 32 + 8 * q + 4 * g) * 4) =
+                    make_float4(acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]);
+#pragma unroll 4
+        for (int p = 0; p < 8; ++p) {
+            const int rl = p * 4 + erow0, m = m0 + wm * 128 + tm * 32 + rl;
+            const float4 t4 = *reinterpret_cast<const float4*>(er + rl * EROW + ec * 4);
+            if (m < M && n < N) {
+                float v[4] = {t4.x + bb[0], t4.y + bb[1], t4.z + bb[2], t4.w + bb[3]};
+                const size_t o = (size_t)m * N + n;
+                if (EPI == MBX_EPI_STORE) {
+                    store4<bf16_t>(out_t + o, v);
+                } else if (EPI == MBX_EPI_GELU) {
+                    store4<bf16_t>(out_t + o, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                    store4<bf16_t>(out2_t + o, v);
+                } else if (EPI == MBX_EPI_RESID) {
+                    float r[4];
+                    load4<float>(resid + o, r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r[e];
+                    store4<float>(out_f + o, v);
+                } else if (EPI == MBX_EPI_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                    store4<float>(out_f + o, v);
+                } else if (EPI == MBX_EPI_DGELU) {
+                    float u[4];
+                    load4<bf16_t>(aux + o, u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(u[e]);
+                    store4<bf16_t>(out_t + o, v);
+                }
+            }
+        }
+    }
+}
+
 template <typename K>
 static int set_lds_attr(K kernel, size_t bytes, const char* who) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -226,8 +361,38 @@ static int set_lds_attr(K kernel, size_t bytes, const char* who) {
     return 0;
 }
 
+static int launch_nt256(const void* a, const void* w, const float* bias, int epi, void* out_t, void* out2_t, float* out_f,
+                        const float* resid, const void* aux, int M, int N, int K, hipStream_t s) {
+    const int ntn = (N + Q_BN - 1) / Q_BN, ntm = (M + Q_BM - 1) / Q_BM;
+    dim3 grid((unsigned)ntn * ntm), block(512);
+    const size_t shm = Q_NSTAGE * Q_STAGE;
+#define MBX_Q_CASE(E)                                                                                                 \
+    case E:                                                                                                           \
+        if (set_lds_attr(gemm_nt_pipe256_kernel<E>, shm, "gemm_nt_pipe256")) return 1;                                \
+        hipLaunchKernelGGL((gemm_nt_pipe256_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w, bias, \
+                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn);          \
+        break;
+    switch (epi) {
+        MBX_Q_CASE(MBX_EPI_STORE)
+        MBX_Q_CASE(MBX_EPI_GELU)
+        MBX_Q_CASE(MBX_EPI_RESID)
+        MBX_Q_CASE(MBX_EPI_TANH)
+        MBX_Q_CASE(MBX_EPI_DGELU)
+        default: return mbx_set_error("gemm_nt: unknown epilogue %d", epi);
+    }
+#undef MBX_Q_CASE
+    MBX_LAUNCH_CHECK("gemm_nt_pipe256");
+    return 0;
+}
+
 int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int epi, void* out_t, void* out2_t, float* out_f,
                             const float* resid, const void* aux, int M, int N, int K, hipStream_t s) {
+    static const int use256 = [] { const char* e = getenv("MBX_NT256"); return e ? atoi(e) : 1; }();
+    // measured (tools/gemm_bench.py, M = 264k): the 256 x 256 kernel wins 8-11 % where the epilogue only stores
+    // (qkv, fc1, dX GEMMs); with a second HBM stream in the epilogue (residual / GELU' input) two smaller
+    // workgroups per CU are faster.
+    const bool light_epi = epi == MBX_EPI_STORE || epi == MBX_EPI_GELU || epi == MBX_EPI_TANH;
+    if (use256 && light_epi && N >= 256) return launch_nt256(a, w, bias, epi, out_t, out2_t, out_f, resid, aux, M, N, K, s);
     const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
     const size_t shm = P_NSTAGE * P_STAGE;
