@@ -354,6 +354,185 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pipe256_kernel(const bf16_t* _
     }
 }
 
+// ================================================================================================
+// gemm_nt_persist: persistent 256 x 256 kernel for the store-only epilogues (bf16 outputs: STORE, GELU).
+//
+// Measured on this chip (tools/probes/mfma_dma.hip, MBX_DBG ablations, MBX_TRACE stamps):
+//   * LDS-DMA out of L2 sustains ~20 B/clk/CU beside a running MFMA loop -> the k-loop of a 256 x 256 tile
+//     tops out near 1.3 PFLOP/s, a 256 x 128 tile near 1.0;
+//   * the epilogue of a tile is HBM-write-bound (~3.9 TB/s chip-wide) and a CU's vector-memory pipe is in
+//     order: while a workgroup bursts its stores, the LDS-DMA loads of every workgroup on that CU queue
+//     behind them, so "loop + epilogue" times ADD (0.50 + 0.21 ms for the QKV GEMM) whatever the occupancy.
+// Hence: one persistent workgroup per CU walks its tiles; the LDS-DMA ring runs across tile boundaries
+// (no pipeline refill per tile), and a finished tile is kept as packed bf16 in 64 VGPRs and TRICKLED out
+// two 8-byte stores per wave per k-iteration during the next tile's first 16 k-iterations, so the store
+// queue never backs up and the DMA stream is never blocked.  vmcnt is in order on gfx950 and counts stores:
+// the waits use the count of LDS-DMA groups only (8 = two groups), which is conservative whatever number
+// of stores was actually issued (predicated-off stores may be skipped).
+// ================================================================================================
+typedef unsigned u32x2v_t __attribute__((ext_vector_type(2)));
+static constexpr int R_BIAS_OFF = Q_NSTAGE * Q_STAGE;          // bias staged in LDS behind the ring (<= 2048 floats)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                 const float* __restrict__ bias, bf16_t* __restrict__ out_t,
+                                                                 bf16_t* __restrict__ out2_t, int M, int N, int K, int ntn,
+                                                                 int ntiles, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 stages x 32 KiB + bias
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int i = lane & 31, g = lane >> 5;
+    const int lr = lane >> 2, lp = lane & 3;
+    float* sbias = reinterpret_cast<float*>(smem + R_BIAS_OFF);
+    for (int c = tid; c < N; c += 512) sbias[c] = bias ? bias[c] : 0.f;
+
+    const int nk = K / Q_BK;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles v = blockIdx.x + j * gridDim.x
+    const int f_total = my_tiles * nk;
+
+    // ---- LDS-DMA issue state (runs three k-tiles ahead of the compute state, across tile boundaries) ----
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
+    int is_j = 0, is_kt = 0, is_stage = 0;
+    char* dstA = smem + wave * 32 * P_ROWB;
+    char* dstW = smem + Q_A_BYTES + wave * 32 * P_ROWB;
+#define R_SETUP(j_)                                                                    \
+    do {                                                                               \
+        const int lid_ = xcd_remap2((int)blockIdx.x + (j_) * (int)gridDim.x, ntiles);  \
+        const int n0_ = (lid_ % ntn) * Q_BN, m0_ = (lid_ / ntn) * Q_BM;                \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                             \
+            const int row_ = wave * 32 + q_ * 16 + lr;                                 \
+            const int sw_ = (lp ^ ((row_ >> 2) & 3)) << 3;                             \
+            srcA[q_] = A + (size_t)min(m0_ + row_, M - 1) * K + sw_;                   \
+            srcW[q_] = W + (size_t)min(n0_ + row_, N - 1) * K + sw_;                   \
+        }                                                                              \
+    } while (0)
+#define R_ISSUE()                                                                      \
+    do {                                                                               \
+        const size_t ko_ = (size_t)is_kt * Q_BK;                                       \
+        GLDS16(srcA[0] + ko_, dstA + is_stage * Q_STAGE);                              \
+        GLDS16(srcA[1] + ko_, dstA + is_stage * Q_STAGE + 1024);                       \
+        GLDS16(srcW[0] + ko_, dstW + is_stage * Q_STAGE);                              \
+        GLDS16(srcW[1] + ko_, dstW + is_stage * Q_STAGE + 1024);                       \
+        is_stage = (is_stage + 1) & 3;                                                 \
+        if (++is_kt == nk) { is_kt = 0; ++is_j; if (is_j < my_tiles) R_SETUP(is_j); }  \
+    } while (0)
+
+    if (my_tiles > 0) R_SETUP(0);
+    int issued = 0;
+    for (; issued < 3 && issued < f_total; ++issued) R_ISSUE();
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    uint32_t pend[2][4][8];          // previous tile, bf16 pairs: pend[tn][tm][2 q + h] = columns 8 q + 4 g + 2 h, +1
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pend[a][b][r] = 0u;
+    bool pend_valid = false;
+    int pm0 = 0, pn0 = 0;
+
+    // one 8-byte store (two for GELU) of the pending tile: piece = (tn, tm, q), compile-time constants
+#define R_EMIT(tn_, tm_, q_)                                                                               \
+    do {                                                                                                   \
+        const int m_ = pm0 + wm * 128 + (tm_) * 32 + i, n_ = pn0 + wn * 64 + (tn_) * 32 + 8 * (q_) + 4 * g;   \
+        if (pend_valid && m_ < M && n_ < N && !(dbg & 4)) {                                                \
+            const uint32_t lo_ = pend[tn_][tm_][2 * (q_)], hi_ = pend[tn_][tm_][2 * (q_) + 1];             \
+            const size_t o_ = (dbg & 8) ? ((size_t)(m_ & 255) * N + n_) : ((size_t)m_ * N + n_);           \
+            { const u32x2v_t v2_ = {lo_, hi_};                                                             \
+              if (dbg & 32) __builtin_nontemporal_store(v2_, reinterpret_cast<u32x2v_t*>(out_t + o_));     \
+              else *reinterpret_cast<u32x2v_t*>(out_t + o_) = v2_; }                                       \
+            if (EPI == MBX_EPI_GELU) {                                                                     \
+                const float u0_ = __uint_as_float(lo_ << 16), u1_ = __uint_as_float(lo_ & 0xffff0000u);    \
+                const float u2_ = __uint_as_float(hi_ << 16), u3_ = __uint_as_float(hi_ & 0xffff0000u);    \
+                *reinterpret_cast<uint2*>(out2_t + o_) =                                                   \
+                    make_uint2(pack_bf2(gelu_fast(u0_), gelu_fast(u1_)), pack_bf2(gelu_fast(u2_), gelu_fast(u3_)));   \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+
+    // one k-iteration; KI (0..15) selects which two pieces of the pending tile are stored when TRICKLE is set
+#define R_ITER(KI, TRICKLE)                                                                                \
+    do {                                                                                                   \
+        const int ahead_ = f_total - 1 - f;                                                                \
+        if (ahead_ >= 2) WAIT_VMCNT(8); else if (ahead_ == 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);           \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        if (issued < f_total) { R_ISSUE(); ++issued; }                                                     \
+        const char* sA_ = smem + stage * Q_STAGE;                                                          \
+        const char* sW_ = sA_ + Q_A_BYTES;                                                                 \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                 \
+            bf16x8_t fw_[2], fa_[4];                                                                       \
+            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                               \
+                fw_[t_] = *reinterpret_cast<const bf16x8_t*>(sW_ + sw_off(wn * 64 + t_ * 32 + i, 2 * s_ + g));   \
+            _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)                                               \
+                fa_[t_] = *reinterpret_cast<const bf16x8_t*>(sA_ + sw_off(wm * 128 + t_ * 32 + i, 2 * s_ + g));  \
+            _Pragma("unroll") for (int tn_ = 0; tn_ < 2; ++tn_)                                            \
+                _Pragma("unroll") for (int tm_ = 0; tm_ < 4; ++tm_)                                        \
+                    acc[tn_][tm_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw_[tn_], fa_[tm_], acc[tn_][tm_], 0, 0, 0);   \
+        }                                                                                                  \
+        if (TRICKLE) {                                                                                     \
+            /* piece order: a 128-byte output line (64 columns = tn 0..1 x q 0..3 of one row) completes within 4 iterations */ \
+            R_EMIT(((2 * (KI)) >> 2) & 1, ((2 * (KI)) >> 3) & 3, (2 * (KI)) & 3);                          \
+            if (!(dbg & 16)) R_EMIT(((2 * (KI) + 1) >> 2) & 1, ((2 * (KI) + 1) >> 3) & 3, (2 * (KI) + 1) & 3);   \
+        }                                                                                                  \
+        stage = (stage + 1) & 3;                                                                           \
+        ++f;                                                                                               \
+    } while (0)
+
+    __syncthreads();   // bias staged
+    int stage = 0, f = 0;
+    for (int j = 0; j < my_tiles; ++j) {
+        // first 16 k-iterations: compute this tile, trickle the previous one
+        R_ITER(0, true);  R_ITER(1, true);  R_ITER(2, true);  R_ITER(3, true);
+        R_ITER(4, true);  R_ITER(5, true);  R_ITER(6, true);  R_ITER(7, true);
+        R_ITER(8, true);  R_ITER(9, true);  R_ITER(10, true); R_ITER(11, true);
+        R_ITER(12, true); R_ITER(13, true); R_ITER(14, true); R_ITER(15, true);
+        for (int kt = 16; kt < nk; ++kt) R_ITER(0, false);
+        // tile finished: accumulators (+ bias) -> packed bf16 pending registers
+        const int lid = xcd_remap2((int)blockIdx.x + j * (int)gridDim.x, ntiles);
+        pn0 = (lid % ntn) * Q_BN;
+        pm0 = (lid / ntn) * Q_BM;
+        pend_valid = true;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nc = min(pn0 + wn * 64 + tn * 32 + 8 * q + 4 * g, N - 4);
+                const float4 b4 = *reinterpret_cast<const float4*>(sbias + nc);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    pend[tn][tm][2 * q] = pack_bf2(acc[tn][tm][4 * q] + b4.x, acc[tn][tm][4 * q + 1] + b4.y);
+                    pend[tn][tm][2 * q + 1] = pack_bf2(acc[tn][tm][4 * q + 2] + b4.z, acc[tn][tm][4 * q + 3] + b4.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
+    // last tile: nothing left to hide behind -> plain burst
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R_EMIT(tn, tm, q);
+#undef R_ITER
+#undef R_EMIT
+#undef R_ISSUE
+#undef R_SETUP
+}
+
 template <typename K>
 static int set_lds_attr(K kernel, size_t bytes, const char* who) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -391,6 +570,24 @@ int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int
     // measured (tools/gemm_bench.py, M = 264k): the 256 x 256 kernel wins 8-11 % where the epilogue only stores
     // (qkv, fc1, dX GEMMs); with a second HBM stream in the epilogue (residual / GELU' input) two smaller
     // workgroups per CU are faster.
+    static const int persist = [] { const char* e = getenv("MBX_NT_PERSIST"); return e ? atoi(e) : 0; }();   // experiment, off: see DESIGN.md
+    if (persist && (epi == MBX_EPI_STORE || epi == MBX_EPI_GELU) && N >= 256 && N <= 2048 && N % 4 == 0 && K % (16 * Q_BK) == 0) {
+        const int ntn_p = (N + Q_BN - 1) / Q_BN, ntiles = ntn_p * ((M + Q_BM - 1) / Q_BM);
+        const int grid_p = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
+        const size_t shm_p = R_BIAS_OFF + 2048 * sizeof(float);
+        static const int dbg_p = [] { const char* e = getenv("MBX_DBG"); return e ? atoi(e) : 0; }();
+        if (epi == MBX_EPI_STORE) {
+            if (set_lds_attr(gemm_nt_persist_kernel<MBX_EPI_STORE>, shm_p, "gemm_nt_persist")) return 1;
+            hipLaunchKernelGGL((gemm_nt_persist_kernel<MBX_EPI_STORE>), dim3(grid_p), dim3(512), shm_p, s, (const bf16_t*)a,
+                               (const bf16_t*)w, bias, (bf16_t*)out_t, (bf16_t*)out2_t, M, N, K, ntn_p, ntiles, dbg_p);
+        } else {
+            if (set_lds_attr(gemm_nt_persist_kernel<MBX_EPI_GELU>, shm_p, "gemm_nt_persist")) return 1;
+            hipLaunchKernelGGL((gemm_nt_persist_kernel<MBX_EPI_GELU>), dim3(grid_p), dim3(512), shm_p, s, (const bf16_t*)a,
+                               (const bf16_t*)w, bias, (bf16_t*)out_t, (bf16_t*)out2_t, M, N, K, ntn_p, ntiles, dbg_p);
+        }
+        MBX_LAUNCH_CHECK("gemm_nt_persist");
+        return 0;
+    }
     const bool light_epi = epi == MBX_EPI_STORE || epi == MBX_EPI_GELU || epi == MBX_EPI_TANH;
     if (use256 && light_epi && N >= 256) return launch_nt256(a, w, bias, epi, out_t, out2_t, out_f, resid, aux, M, N, K, s);
     const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
@@ -596,9 +793,143 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __re
         }
 }
 
+// ================================================================================================
+// gemm_tn_pipe256: 256 (n) x 256 (k) output tile, stage = dY [32 tokens][256 n] + A [32 tokens][256 k] (32 KiB),
+// 4-stage ring, waves 2 (n) x 4 (k) with 128 x 64 wave tiles: 12 transpose reads per 8 MFMAs instead of 8 per 4
+// (the 256 x 128 kernel saturates the LDS: 64 ds_read_b64_tr_b16 per wave per 16 MFMAs) and 1/3 less LDS-DMA.
+// ================================================================================================
+static constexpr int U_BN = 256, U_BK = 256, U_BMS = 32;
+static constexpr int U_TILE = U_BMS * 512, U_STAGE = 2 * U_TILE;   // 16 KiB per operand tile, 32 KiB per stage
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A,
+                                                                 float* __restrict__ part_w, float* __restrict__ part_b, int M,
+                                                                 int N, int K, int ntk, int ntiles, int nsplits,
+                                                                 int chunks_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 stages x 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int split = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
+    if (split >= nsplits) return;
+    const int n0 = (tile / ntk) * U_BN, k0 = (tile % ntk) * U_BK;
+    const int wr = wave >> 2, wc = wave & 3;   // wave tile: n rows [128 wr, +128), k cols [64 wc, +64)
+    const int nchunks = (M + U_BMS - 1) / U_BMS;
+    const int c_beg = split * chunks_per_split, c_end = min(nchunks, c_beg + chunks_per_split);
+    const int nc = c_end - c_beg;
+
+    // LDS-DMA: each operand tile = 16 instructions of 1 KiB (2 token rows of 512 B); wave w: rows 4 w + 2 i + (lane >> 5)
+    int rowv[2];
+    size_t ycol[2], acol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rowv[i] = wave * 4 + 2 * i + (lane >> 5);
+        const int lc = (lane & 31) ^ ((rowv[i] & 3) << 2);
+        ycol[i] = (size_t)min(n0 + lc * 8, N - 8);
+        acol[i] = (size_t)min(k0 + lc * 8, K - 8);
+    }
+    char* dstY = smem + wave * 4 * 512;
+    char* dstA = dstY + U_TILE;
+#define U_ISSUE(chunk_, stage_)                                                                      \
+    do {                                                                                             \
+        const int mb_ = (chunk_) * U_BMS;                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                           \
+            const size_t r_ = (size_t)min(mb_ + rowv[i_], M - 1);                                    \
+            GLDS16(dY + r_ * N + ycol[i_], dstY + (stage_) * U_STAGE + i_ * 1024);                   \
+            GLDS16(A + r_ * K + acol[i_], dstA + (stage_) * U_STAGE + i_ * 1024);                    \
+        }                                                                                            \
+    } while (0)
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool want_db = (part_b != nullptr) && (k0 == 0) && (wc == 0);
+    f32x16_t accb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[a][r] = 0.f;
+    union { uint32_t u[4]; bf16x8_t v; } ones;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;
+
+    if (nc > 0) U_ISSUE(c_beg, 0);
+    if (nc > 1) U_ISSUE(c_beg + 1, 1);
+    if (nc > 2) U_ISSUE(c_beg + 2, 2);
+    int stage = 0;
+    for (int c = 0; c < nc; ++c) {
+        const int ahead = nc - 1 - c;
+        if (ahead >= 2) WAIT_VMCNT(8); else if (ahead == 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (c + 3 < nc) U_ISSUE(c_beg + c + 3, (stage + 3) & 3);
+        const char* sY = smem + stage * U_STAGE;
+        const char* sA = sY + U_TILE;
+        const int valid = M - (c_beg + c) * U_BMS;   // tokens of this chunk that exist
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t fy[4], fa[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fy[t] = tr_frag<512>(sY, 16 * s, wr * 128 + t * 32, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fa[t] = tr_frag<512>(sA, 16 * s, wc * 64 + t * 32, lane);
+            if (valid < U_BMS) {
+                const int tb = 16 * s + 8 * (lane >> 5);
+                union { bf16x8_t v; uint16_t h[8]; } z;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    z.v = fy[t];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (tb + e >= valid) z.h[e] = 0;
+                    fy[t] = z.v;
+                }
+            }
+#pragma unroll
+            for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc)
+                    acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[tr], fa[tc], acc[tr][tc], 0, 0, 0);
+            if (want_db) {
+#pragma unroll
+                for (int tr = 0; tr < 4; ++tr) accb[tr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[tr], ones.v, accb[tr], 0, 0, 0);
+            }
+        }
+        stage = (stage + 1) & 3;
+    }
+#undef U_ISSUE
+    const int i = lane & 31, g = lane >> 5;
+    if (want_db && i == 0) {
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 128 + tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (n < N) part_b[(size_t)split * N + n] = accb[tr][r];
+            }
+    }
+    float* pw = part_w + (size_t)split * N * K;
+#pragma unroll
+    for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) {
+            const int k = k0 + wc * 64 + tc * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 128 + tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (k < K && n < N) pw[(size_t)n * K + k] = acc[tr][tc][r];
+            }
+        }
+}
+
+static bool tn_use256(int N, int K) {
+    static const int en = [] { const char* e = getenv("MBX_TN256"); return e ? atoi(e) : 1; }();
+    return en && N >= 256 && K >= 256;
+}
 static int tnp_splits(int M, int N, int K) {
-    const int tiles = ((N + T_BN - 1) / T_BN) * ((K + T_BK - 1) / T_BK);
-    const int nchunks = (M + T_BMS - 1) / T_BMS;
+    const bool big = tn_use256(N, K);
+    const int tiles = big ? ((N + U_BN - 1) / U_BN) * ((K + U_BK - 1) / U_BK) : ((N + T_BN - 1) / T_BN) * ((K + T_BK - 1) / T_BK);
+    const int nchunks = big ? (M + U_BMS - 1) / U_BMS : (M + T_BMS - 1) / T_BMS;
     int s = ((512 / tiles + 7) / 8) * 8;   // ~2 waves of workgroups over the 256 CUs, a multiple of the 8 XCDs
     if (s > 128) s = 128;
     if (s > nchunks) s = nchunks;
@@ -610,12 +941,26 @@ size_t mbx_gemm_tn_pipe_ws(int M, int N, int K) {
     return (sp * N * K + sp * N) * sizeof(float) + 256;
 }
 int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, void* ws, hipStream_t s) {
-    const int ntn = (N + T_BN - 1) / T_BN, ntk = (K + T_BK - 1) / T_BK;
+    const bool big = tn_use256(N, K);
+    const int ntn = big ? (N + U_BN - 1) / U_BN : (N + T_BN - 1) / T_BN, ntk = big ? (K + U_BK - 1) / U_BK : (K + T_BK - 1) / T_BK;
     const int splits = tnp_splits(M, N, K);
-    const int nchunks = (M + T_BMS - 1) / T_BMS;
+    const int nchunks = big ? (M + U_BMS - 1) / U_BMS : (M + T_BMS - 1) / T_BMS;
     const int cps = (nchunks + splits - 1) / splits;
     float* part_w = splits == 1 ? dw : (float*)ws;
     float* part_b = db ? (splits == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
+    if (big) {
+        const size_t shm256 = 4 * U_STAGE;
+        if (set_lds_attr(gemm_tn_pipe256_kernel, shm256, "gemm_tn_pipe256")) return 1;
+        const int ntiles256 = ntn * ntk, groups256 = (splits + 7) / 8;
+        hipLaunchKernelGGL(gemm_tn_pipe256_kernel, dim3(8 * groups256 * ntiles256), dim3(512), shm256, s, (const bf16_t*)dy,
+                           (const bf16_t*)a, part_w, part_b, M, N, K, ntk, ntiles256, splits, cps);
+        MBX_LAUNCH_CHECK("gemm_tn_pipe256");
+        if (splits > 1) {
+            if (mbx_launch_colsum(part_w, splits, N * K, 0, N * K, dw, s)) return 1;
+            if (db && mbx_launch_colsum(part_b, splits, N, 0, N, db, s)) return 1;
+        }
+        return 0;
+    }
     const size_t shm = 3 * T_STAGE;
     static const int dbg = [] { const char* e = getenv("MBX_DBG"); return e ? atoi(e) : 0; }();
     if (set_lds_attr(gemm_tn_pipe_kernel, shm, "gemm_tn_pipe")) return 1;
