@@ -70,6 +70,8 @@ class TimedOps:
     def __init__(self, ops):
         self._ops, self.rec = ops, []
 
+    multi_stream = False   # event pairs must not overlap: the instrumented step runs on one stream
+
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
         if not callable(fn) or name.startswith('_'):
@@ -246,10 +248,8 @@ def main():
     if rank == 0:
         timed = TimedOps(hip_ops.get())
         opt.zero_grad(set_to_none=True)
-        os.environ['MBX_DUAL_STREAM'] = '0'      # serialise the two streams so that the event pairs do not overlap
         loss = pose_loss(M.run(timed, model, x), gt)
         loss.backward()
-        os.environ.pop('MBX_DUAL_STREAM', None)
         agg = timed.summary()
         tot = sum(d['ms'] for d in agg.values())
         breakdown = {k: dict(calls=d['calls'], ms=round(d['ms'], 3), share=round(d['ms'] / tot, 4)) for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}

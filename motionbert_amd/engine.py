@@ -110,7 +110,7 @@ class Engine:
         # The st and ts blocks of a level are independent (DSTformer.py:341-342 feeds both the same x): with
         # MBX_DUAL_STREAM=1 the ts block runs on a second HIP stream so that HBM-bound kernels of one stream
         # (LayerNorm, GEMM epilogues) overlap MFMA-bound kernels of the other.
-        self.dual = os.environ.get('MBX_DUAL_STREAM', '1') == '1'
+        self.dual = os.environ.get('MBX_DUAL_STREAM', '1') == '1' and getattr(ops, 'multi_stream', False)
         # weight-gradient GEMMs feed nothing downstream in backward: MBX_WGRAD_STREAM=1 issues them on a third stream
         self.wgrad_async = os.environ.get('MBX_WGRAD_STREAM', '0') == '1'
 

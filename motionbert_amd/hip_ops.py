@@ -69,6 +69,8 @@ def _p(t: Optional[torch.Tensor]):
 class HipOps:
     """Kernel provider backed by libmbx.so.  Stateless apart from size caches."""
 
+    multi_stream = True   # every call takes the current stream: safe to drive from several HIP streams
+
     def __init__(self, lib: Optional[C.CDLL] = None):
         self.lib = lib or load_library()
         self._ws_cache: Dict[tuple, int] = {}
