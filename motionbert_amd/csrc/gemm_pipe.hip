@@ -365,13 +365,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pipe256_kernel(const bf16_t* _
 //     behind them, so "loop + epilogue" times ADD (0.50 + 0.21 ms for the QKV GEMM) whatever the occupancy.
 // Hence: one persistent workgroup per CU walks its tiles; the LDS-DMA ring runs across tile boundaries
 // (no pipeline refill per tile), and a finished tile is kept as packed bf16 in 64 VGPRs and TRICKLED out
-// two 8-byte stores per wave per k-iteration during the next tile's first 16 k-iterations, so the store
-// queue never backs up and the DMA stream is never blocked.  vmcnt is in order on gfx950 and counts stores:
-// the waits use the count of LDS-DMA groups only (8 = two groups), which is conservative whatever number
-// of stores was actually issued (predicated-off stores may be skipped).
+// during the next tile's first 16 k-iterations (through a small LDS staging tile so that every store
+// instruction writes complete 128-byte lines), so the store queue never backs up.  The stores are issued
+// BEFORE the iteration's LDS-DMA group: vmcnt is in order on gfx950 and counts stores, so "at most the two
+// newest DMA groups in flight" is still vmcnt(8) however many stores were actually issued.
 // ================================================================================================
 typedef unsigned u32x2v_t __attribute__((ext_vector_type(2)));
-static constexpr int R_BIAS_OFF = Q_NSTAGE * Q_STAGE;          // bias staged in LDS behind the ring (<= 2048 floats)
+static constexpr int R_STAGE_OFF = Q_NSTAGE * Q_STAGE;                 // 8 waves x [16][64] bf16 staging tiles (18 KiB)
+static constexpr int R_BIAS_OFF = R_STAGE_OFF + 8 * 16 * (64 * 2 + 16);  // bias behind it (<= 1536 floats)
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
@@ -439,31 +440,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(const bf16_t* _
     bool pend_valid = false;
     int pm0 = 0, pn0 = 0;
 
-    // one 8-byte store (two for GELU) of the pending tile: piece = (tn, tm, q), compile-time constants
-#define R_EMIT(tn_, tm_, q_)                                                                               \
+    // ---- trickled, COALESCED stores of the pending tile -------------------------------------------------
+    // (a first version stored the accumulator layout directly, 16-byte pieces of 32 rows per instruction:
+    //  PMC showed 1.29 GB written for 0.81 GB of output plus 0.2 GB of read-for-ownership fetches, because
+    //  partially written lines were evicted from L2 -- and it was slower than the burst epilogue.)
+    // The pending tile (packed bf16 in `pend`) goes out in 8 half-blocks of 16 rows per wave: in k-iteration
+    // 2h the 32 lanes owning those rows drop their 8 quads into a wave-private [16][64] staging tile in LDS,
+    // in k-iteration 2h+1 every lane reads 16 contiguous bytes back and stores them: one instruction covers
+    // 8 complete 128-byte lines.
+    constexpr int SROW = 64 * 2 + 16;                                  // staging row: 64 bf16 + pad
+    char* stg = smem + R_STAGE_OFF + wave * (16 * SROW);
+#define R_STAGE_WRITE(H_)                                                                                  \
     do {                                                                                                   \
-        const int m_ = pm0 + wm * 128 + (tm_) * 32 + i, n_ = pn0 + wn * 64 + (tn_) * 32 + 8 * (q_) + 4 * g;   \
-        if (pend_valid && m_ < M && n_ < N && !(dbg & 4)) {                                                \
-            const uint32_t lo_ = pend[tn_][tm_][2 * (q_)], hi_ = pend[tn_][tm_][2 * (q_) + 1];             \
-            const size_t o_ = (dbg & 8) ? ((size_t)(m_ & 255) * N + n_) : ((size_t)m_ * N + n_);           \
-            { const u32x2v_t v2_ = {lo_, hi_};                                                             \
-              if (dbg & 32) __builtin_nontemporal_store(v2_, reinterpret_cast<u32x2v_t*>(out_t + o_));     \
-              else *reinterpret_cast<u32x2v_t*>(out_t + o_) = v2_; }                                       \
-            if (EPI == MBX_EPI_GELU) {                                                                     \
-                const float u0_ = __uint_as_float(lo_ << 16), u1_ = __uint_as_float(lo_ & 0xffff0000u);    \
-                const float u2_ = __uint_as_float(hi_ << 16), u3_ = __uint_as_float(hi_ & 0xffff0000u);    \
-                *reinterpret_cast<uint2*>(out2_t + o_) =                                                   \
-                    make_uint2(pack_bf2(gelu_fast(u0_), gelu_fast(u1_)), pack_bf2(gelu_fast(u2_), gelu_fast(u3_)));   \
+        if (pend_valid && ((i >> 4) == ((H_) & 1))) {                                                      \
+            _Pragma("unroll") for (int tn_ = 0; tn_ < 2; ++tn_)                                            \
+                _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                           \
+                    *reinterpret_cast<uint2*>(stg + (i & 15) * SROW + (tn_ * 32 + 8 * q_ + 4 * g) * 2) =   \
+                        make_uint2(pend[tn_][(H_) >> 1][2 * q_], pend[tn_][(H_) >> 1][2 * q_ + 1]);        \
+        }                                                                                                  \
+    } while (0)
+#define R_STAGE_STORE(H_)                                                                                  \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int ps_ = 0; ps_ < 2; ++ps_) {                                              \
+            const int rl_ = ps_ * 8 + (lane >> 3);                                                         \
+            const uint4 v_ = *reinterpret_cast<const uint4*>(stg + rl_ * SROW + (lane & 7) * 16);          \
+            const int m_ = pm0 + wm * 128 + ((H_) >> 1) * 32 + ((H_) & 1) * 16 + rl_;                      \
+            const int n_ = pn0 + wn * 64 + (lane & 7) * 8;                                                 \
+            if (pend_valid && m_ < M && n_ < N) {                                                          \
+                const size_t o_ = (size_t)m_ * N + n_;                                                     \
+                *reinterpret_cast<uint4*>(out_t + o_) = v_;                                                \
+                if (EPI == MBX_EPI_GELU) {                                                                 \
+                    const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                                       \
+                    uint32_t g_[4];                                                                        \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                       \
+                        g_[e_] = pack_bf2(gelu_fast(__uint_as_float(w_[e_] << 16)), gelu_fast(__uint_as_float(w_[e_] & 0xffff0000u))); \
+                    *reinterpret_cast<uint4*>(out2_t + o_) = make_uint4(g_[0], g_[1], g_[2], g_[3]);       \
+                }                                                                                          \
             }                                                                                              \
         }                                                                                                  \
     } while (0)
 
-    // one k-iteration; KI (0..15) selects which two pieces of the pending tile are stored when TRICKLE is set
+    // one k-iteration; KI (0..15): even KI stages half-block KI/2 of the pending tile, odd KI stores it
 #define R_ITER(KI, TRICKLE)                                                                                \
     do {                                                                                                   \
         const int ahead_ = f_total - 1 - f;                                                                \
         if (ahead_ >= 2) WAIT_VMCNT(8); else if (ahead_ == 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);           \
         __builtin_amdgcn_s_barrier();                                                                      \
+        if (TRICKLE) { if (((KI) & 1) == 0) R_STAGE_WRITE((KI) >> 1); else R_STAGE_STORE((KI) >> 1); }     \
         if (issued < f_total) { R_ISSUE(); ++issued; }                                                     \
         const char* sA_ = smem + stage * Q_STAGE;                                                          \
         const char* sW_ = sA_ + Q_A_BYTES;                                                                 \
@@ -476,11 +499,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(const bf16_t* _
             _Pragma("unroll") for (int tn_ = 0; tn_ < 2; ++tn_)                                            \
                 _Pragma("unroll") for (int tm_ = 0; tm_ < 4; ++tm_)                                        \
                     acc[tn_][tm_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw_[tn_], fa_[tm_], acc[tn_][tm_], 0, 0, 0);   \
-        }                                                                                                  \
-        if (TRICKLE) {                                                                                     \
-            /* piece order: a 128-byte output line (64 columns = tn 0..1 x q 0..3 of one row) completes within 4 iterations */ \
-            R_EMIT(((2 * (KI)) >> 2) & 1, ((2 * (KI)) >> 3) & 3, (2 * (KI)) & 3);                          \
-            if (!(dbg & 16)) R_EMIT(((2 * (KI) + 1) >> 2) & 1, ((2 * (KI) + 1) >> 3) & 3, (2 * (KI) + 1) & 3);   \
         }                                                                                                  \
         stage = (stage + 1) & 3;                                                                           \
         ++f;                                                                                               \
@@ -520,15 +538,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(const bf16_t* _
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     }
-    // last tile: nothing left to hide behind -> plain burst
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) R_EMIT(tn, tm, q);
+    // last tile: nothing left to hide behind -> the same staged stores as one burst
+    R_STAGE_WRITE(0); R_STAGE_STORE(0); R_STAGE_WRITE(1); R_STAGE_STORE(1);
+    R_STAGE_WRITE(2); R_STAGE_STORE(2); R_STAGE_WRITE(3); R_STAGE_STORE(3);
+    R_STAGE_WRITE(4); R_STAGE_STORE(4); R_STAGE_WRITE(5); R_STAGE_STORE(5);
+    R_STAGE_WRITE(6); R_STAGE_STORE(6); R_STAGE_WRITE(7); R_STAGE_STORE(7);
+#undef R_STAGE_WRITE
+#undef R_STAGE_STORE
 #undef R_ITER
-#undef R_EMIT
 #undef R_ISSUE
 #undef R_SETUP
 }
@@ -571,10 +588,10 @@ int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int
     // (qkv, fc1, dX GEMMs); with a second HBM stream in the epilogue (residual / GELU' input) two smaller
     // workgroups per CU are faster.
     static const int persist = [] { const char* e = getenv("MBX_NT_PERSIST"); return e ? atoi(e) : 0; }();   // experiment, off: see DESIGN.md
-    if (persist && (epi == MBX_EPI_STORE || epi == MBX_EPI_GELU) && N >= 256 && N <= 2048 && N % 4 == 0 && K % (16 * Q_BK) == 0) {
+    if (persist && (epi == MBX_EPI_STORE || epi == MBX_EPI_GELU) && N >= 256 && N <= 1536 && N % 8 == 0 && K % (16 * Q_BK) == 0) {
         const int ntn_p = (N + Q_BN - 1) / Q_BN, ntiles = ntn_p * ((M + Q_BM - 1) / Q_BM);
         const int grid_p = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
-        const size_t shm_p = R_BIAS_OFF + 2048 * sizeof(float);
+        const size_t shm_p = R_BIAS_OFF + 1536 * sizeof(float);
         static const int dbg_p = [] { const char* e = getenv("MBX_DBG"); return e ? atoi(e) : 0; }();
         if (epi == MBX_EPI_STORE) {
             if (set_lds_attr(gemm_nt_persist_kernel<MBX_EPI_STORE>, shm_p, "gemm_nt_persist")) return 1;
@@ -930,7 +947,11 @@ static int tnp_splits(int M, int N, int K) {
     const bool big = tn_use256(N, K);
     const int tiles = big ? ((N + U_BN - 1) / U_BN) * ((K + U_BK - 1) / U_BK) : ((N + T_BN - 1) / T_BN) * ((K + T_BK - 1) / T_BK);
     const int nchunks = big ? (M + U_BMS - 1) / U_BMS : (M + T_BMS - 1) / T_BMS;
-    int s = ((512 / tiles + 7) / 8) * 8;   // ~2 waves of workgroups over the 256 CUs, a multiple of the 8 XCDs
+    // one workgroup per CU: the launch should be an exact number of 256-workgroup waves (measured: 288 blocks
+    // cost 1.10 ms where 768 cost 0.77 ms on the QKV weight gradient) and a multiple of the 8 XCDs
+    int s = ((512 / tiles + 7) / 8) * 8;
+    for (int w = 1; w <= 4; ++w)
+        if ((256 * w) % tiles == 0 && ((256 * w) / tiles) % 8 == 0 && (256 * w) / tiles <= 128) { s = (256 * w) / tiles; break; }
     if (s > 128) s = 128;
     if (s > nchunks) s = nchunks;
     if (s < 1) s = 1;
