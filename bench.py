@@ -257,8 +257,8 @@ def main():
         d = agg['gemm_nt']
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel='gemm_nt_kernel', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                    traffic=None, launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
+        roof = dict(bound='mfma', kernel='mbx_gemm_nt -> gemm_nt_pipe256_kernel / gemm_nt_pipe_kernel (bf16 MFMA GEMM, all 162 launches of a step)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                    traffic=None, traffic_ref='profiles/r01_pmc_bench_v3.txt (FETCH_SIZE x2 + WRITE_SIZE per kernel)', launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
                     flops_per_launch=d['flops'] / d['calls'], dominant_by_time=dom)
     flops_step = 3.0 * model_flops_fwd(FULL, T) * B
     out = {
