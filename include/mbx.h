@@ -32,7 +32,7 @@ enum mbx_dtype { MBX_F32 = 0, MBX_BF16 = 1 };
 /* GEMM epilogues (fused into the store of the accumulator tile) */
 enum mbx_epilogue {
     MBX_EPI_STORE = 0, /* out_t = acc + bias                          qkv (DSTformer.py:103,143) / dX GEMMs */
-    MBX_EPI_GELU  = 1, /* out_t = acc + bias; out2_t = gelu_erf(.)    fc1 + nn.GELU (DSTformer.py:80-81)   */
+    MBX_EPI_GELU  = 1, /* out2_t = gelu_erf(acc + bias); out_t = acc + bias if non-NULL   fc1 + nn.GELU (:80-81) */
     MBX_EPI_RESID = 2, /* out_f = resid + acc + bias                  proj / fc2 + residual (:241-249)     */
     MBX_EPI_TANH  = 3, /* out_f = tanh(acc + bias)                    pre_logits fc + Tanh (:294-297,354)  */
     MBX_EPI_DGELU = 4  /* out_t = acc * gelu_erf'(aux_t)              backward of nn.GELU                  */

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
                 if (EPI == MBX_EPI_STORE) {
                     store4<T>(out_t + o, v);
                 } else if (EPI == MBX_EPI_GELU) {
-                    store4<T>(out_t + o, v);
+                    if (out_t) store4<T>(out_t + o, v);   // pre-activation is only needed for backward
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                     store4<T>(out2_t + o, v);
@@ -242,7 +242,7 @@ extern "C" int mbx_gemm_nt(const void* a, const void* w, const float* bias, int 
     MBX_CHECK_ARG((size_t)M * (size_t)(N > K ? N : K) < ((size_t)1 << 40), "gemm_nt: operand too large");
     switch (epilogue) {
         case MBX_EPI_STORE: MBX_CHECK_ARG(out_t, "gemm_nt: STORE needs out_t"); break;
-        case MBX_EPI_GELU: MBX_CHECK_ARG(out_t && out2_t, "gemm_nt: GELU needs out_t and out2_t"); break;
+        case MBX_EPI_GELU: MBX_CHECK_ARG(out2_t, "gemm_nt: GELU needs out2_t (out_t, the pre-activation, is optional)"); break;
         case MBX_EPI_RESID: MBX_CHECK_ARG(out_f && resid, "gemm_nt: RESID needs out_f and resid"); break;
         case MBX_EPI_TANH: MBX_CHECK_ARG(out_f, "gemm_nt: TANH needs out_f"); break;
         case MBX_EPI_DGELU: MBX_CHECK_ARG(out_t && aux_t, "gemm_nt: DGELU needs out_t and aux_t"); break;

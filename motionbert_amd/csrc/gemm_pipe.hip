@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
                 if (EPI == MBX_EPI_STORE) {
                     store4<bf16_t>(out_t + o, v);
                 } else if (EPI == MBX_EPI_GELU) {
-                    store4<bf16_t>(out_t + o, v);
+                    if (out_t) store4<bf16_t>(out_t + o, v);   // pre-activation is only needed for backward
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                     store4<bf16_t>(out2_t + o, v);
@@ -292,11 +292,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pipe256_kernel(const bf16_t* _
             for (int t = 0; t < 2; ++t) fw[t] = *reinterpret_cast<const bf16x8_t*>(sW + sw_off(wn * 64 + t * 32 + i, 2 * s + g));
 #pragma unroll
             for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const bf16x8_t*>(sA + sw_off(wm * 128 + t * 32 + i, 2 * s + g));
+#ifdef MBX_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+#ifdef MBX_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         stage = (stage + 1) & 3;
     }
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pipe256_kernel(const bf16_t* _
                 if (EPI == MBX_EPI_STORE) {
                     store4<bf16_t>(out_t + o, v);
                 } else if (EPI == MBX_EPI_GELU) {
-                    store4<bf16_t>(out_t + o, v);
+                    if (out_t) store4<bf16_t>(out_t + o, v);   // pre-activation is only needed for backward
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                     store4<bf16_t>(out2_t + o, v);
@@ -588,7 +594,7 @@ int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int
     // (qkv, fc1, dX GEMMs); with a second HBM stream in the epilogue (residual / GELU' input) two smaller
     // workgroups per CU are faster.
     static const int persist = [] { const char* e = getenv("MBX_NT_PERSIST"); return e ? atoi(e) : 0; }();   // experiment, off: see DESIGN.md
-    if (persist && (epi == MBX_EPI_STORE || epi == MBX_EPI_GELU) && N >= 256 && N <= 1536 && N % 8 == 0 && K % (16 * Q_BK) == 0) {
+    if (persist && out_t && (epi == MBX_EPI_STORE || epi == MBX_EPI_GELU) && N >= 256 && N <= 1536 && N % 8 == 0 && K % (16 * Q_BK) == 0) {
         const int ntn_p = (N + Q_BN - 1) / Q_BN, ntiles = ntn_p * ((M + Q_BM - 1) / Q_BM);
         const int grid_p = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
         const size_t shm_p = R_BIAS_OFF + 1536 * sizeof(float);

@@ -236,7 +236,7 @@ class Engine:
         M, C = self.M, cfg.C
         xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
         ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
-        u, g = self._t(M, cfg.hidden), self._t(M, cfg.hidden)
+        u, g = (self._t(M, cfg.hidden) if need_grad else None), self._t(M, cfg.hidden)   # u only feeds GELU' in backward
         ops.gemm_nt(xn, self.Wn[f'{pre}.{mlp}.fc1'], P[f'{pre}.{mlp}.fc1.bias'], EPI_GELU, out_t=u, out2_t=g)
         y = self._f(M, C)
         ops.gemm_nt(g, self.Wn[f'{pre}.{mlp}.fc2'], P[f'{pre}.{mlp}.fc2.bias'], EPI_RESID, resid=x, out_f=y)

@@ -99,7 +99,7 @@ class HipOps:
         ws = [P[n + '.weight'] for n in names]
         dev = ws[0].device
         dt = _DT[tdtype]
-        key = (tuple(w.data_ptr() for w in ws), dt, dev.index)
+        key = (tuple((w.data_ptr(), tuple(w.shape)) for w in ws), dt, dev.index)
         with self._lock:
             ent = self._desc_cache.get(key)
             if ent is None:

@@ -93,8 +93,8 @@ class MockOps:
         if epi == EPI_STORE:
             out_t.copy_(acc.to(out_t.dtype))
         elif epi == EPI_GELU:
-            u = acc.to(out_t.dtype)
-            out_t.copy_(u)
+            if out_t is not None:
+                out_t.copy_(acc.to(out_t.dtype))
             out2_t.copy_(F.gelu(acc).to(out2_t.dtype))   # gelu of the fp32 value, as the kernel epilogue does
         elif epi == EPI_RESID:
             out_f.copy_(resid + acc)

@@ -247,3 +247,31 @@ def test_non_contiguous_and_no_conf_input():
     xs = torch.cat([x, x], -1)[..., :3]       # non-contiguous view
     with torch.no_grad():
         assert torch.equal(model(xs), model(x))
+
+
+def test_hipgraph_replay_matches_eager_and_is_faster():
+    """B=1 clip-at-a-time inference (infer_wild.py:66-88) through a captured hipGraph."""
+    import time
+    from motionbert_amd.graph import GraphedForward
+    model = build_model(FULL, seed=0).to(DEV).eval()
+    x = make_input(1, 243, 17, 8).to(DEV)
+    fast = GraphedForward(model, x)
+    x2 = make_input(1, 243, 17, 9).to(DEV)
+    with torch.no_grad():
+        ref = model(x2)
+    got = fast(x2)
+    assert torch.equal(got, ref)
+    with torch.no_grad():   # weights updated in place are picked up without re-capture
+        model.head.bias.add_(1.0)
+        assert torch.equal(fast(x2), model(x2))
+
+    def timeit(fn, n=20):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    with torch.no_grad():
+        t_eager, t_graph = timeit(lambda: model(x2)), timeit(lambda: fast(x2))
+    REPORT['hipgraph.B1T243'] = dict(eager_ms=t_eager, graph_ms=t_graph)
+    assert t_graph < t_eager
