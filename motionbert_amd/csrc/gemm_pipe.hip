@@ -292,17 +292,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pipe256_kernel(const bf16_t* _
             for (int t = 0; t < 2; ++t) fw[t] = *reinterpret_cast<const bf16x8_t*>(sW + sw_off(wn * 64 + t * 32 + i, 2 * s + g));
 #pragma unroll
             for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const bf16x8_t*>(sA + sw_off(wm * 128 + t * 32 + i, 2 * s + g));
-#ifdef MBX_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
-#ifdef MBX_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
         stage = (stage + 1) & 3;
     }

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmbx.so')
+LIB_PATH = os.environ.get('MBX_LIB', os.path.join(_HERE, 'libmbx.so'))   # MBX_LIB: A/B builds of the kernel library
 
 MBX_F32, MBX_BF16 = 0, 1
 _DT = {torch.float32: MBX_F32, torch.bfloat16: MBX_BF16}

@@ -110,7 +110,10 @@ class _DSTformerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ops, cfg, names, tdtype, return_rep, grad_sync, x, *params):
-        need_grad = any(ctx.needs_input_grad[6:])
+        # needs_input_grad ignores torch.no_grad(): `grad_sync` is (enabled, sync) decided by the caller, where
+        # the grad mode is still visible (autograd switches it off inside Function.forward)
+        grad_enabled, grad_sync = grad_sync
+        need_grad = grad_enabled and any(ctx.needs_input_grad[6:])
         P = dict(zip(names, params))
         eng = Engine(ops, cfg, P, tdtype)
         out, saved = eng.forward(x, return_rep, need_grad)
@@ -164,7 +167,7 @@ def run(ops, model, x, return_rep=False, grad_sync=None):
     told about finished gradient buckets during backward (see motionbert_amd.ddp)."""
     cfg = make_cfg(model)
     names, params = zip(*model.named_parameters())
-    return _DSTformerFn.apply(ops, cfg, names, _DTYPES[model.precision], return_rep, grad_sync, x, *params)
+    return _DSTformerFn.apply(ops, cfg, names, _DTYPES[model.precision], return_rep, (torch.is_grad_enabled(), grad_sync), x, *params)
 
 
 class DSTformer(nn.Module):

@@ -34,6 +34,7 @@ class MockOps:
     # weights -------------------------------------------------------------
     def prep_weights(self, P, names, tdtype, need_t):
         self._log('prep_weights')
+        self.last_need_t = bool(need_t)
         Wn = {n: P[n + '.weight'].detach().to(tdtype).contiguous() for n in names}
         Wt = {n: P[n + '.weight'].detach().t().to(tdtype).contiguous() for n in names} if need_t else {}
         return Wn, Wt

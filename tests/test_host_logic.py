@@ -81,9 +81,13 @@ def test_no_grad_saves_nothing_and_frozen_params_get_none():
     _load(model, z)
     model.precision = 'fp32'
     x = torch.from_numpy(z['x'])
+    ops = MockOps()
     with torch.no_grad():
-        out = M.run(MockOps(), model, x)
+        out = M.run(ops, model, x)
     assert not out.requires_grad
+    # inference must not pay for training: no transposed weight copies, no backward-only tensors
+    assert not any(c.startswith(('gemm_tn', 'attn_bwd')) for c in ops.calls)
+    assert ops.last_need_t is False
     out[:, :, 0, :] = 0  # callers write into the output in place (train.py:76, infer_wild.py:82)
     # partial_train_layers (learning.py:69-77) freezes by name
     for n, p in model.named_parameters():

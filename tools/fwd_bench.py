@@ -15,4 +15,5 @@ with torch.no_grad():
     for _ in range(10): m(x)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 fl = bench.model_flops_fwd(bench.FULL, 243) * B
+print(f'peak HBM {torch.cuda.max_memory_allocated()/2**30:.1f} GiB; ', end='')
 print(f'forward-only B={B}: {dt*1e3:.2f} ms, {B/dt:.1f} clips/s, {fl/dt/1e12:.1f} TFLOP/s = {fl/dt/2.5e15:.1%} of the bf16 MFMA peak')
