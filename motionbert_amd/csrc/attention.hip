@@ -12,7 +12,7 @@
 //     O^T[d][q]    = sum_k V^T[d][k]  P^T[k][q]    A operand: V^T rows from LDS, B operand: P, already in
 //                                                  registers in exactly the layout the MFMA wants
 // so the softmax needs no LDS and only ONE cross-lane exchange (lanes l and l+32 share a query):
-// row max and row sum are in-register reductions followed by a single __shfl_xor(.., 32).
+// row max and row sum are in-register reductions followed by a single v_permlane32_swap (wave_halves).
 // The score matrix [B,H,J,T,T] that the reference materialises (32 MB per clip) never exists;
 // backward recomputes the probabilities from q, k and the saved log-sum-exp.
 //
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
                 s[r] = key < P.L ? s[r] * scale : -INFINITY;
                 mx = fmaxf(mx, s[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // every fragment f < nfr holds >= 1 valid key: finite
+            mx = wave_halves<WaveMax>(mx);   // every fragment f < nfr holds >= 1 valid key: finite
             const float mn = fmaxf(m, mx);
             const float corr = __expf(m - mn);        // first fragment: exp(-inf) = 0
             float ps = 0.f;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
                 MmaCols<T>::run(vt, VSTR, df * 32, f, s, lane, oacc[df]);
             }
         }
-        l += __shfl_xor(l, 32, 64);
+        l = wave_halves<WaveAdd>(l);
         if (qvalid) {
             store_rowfrag<T, HD>(o + tok * C + (size_t)P.h * HD, oacc, 1.0f / l, g);
             if (g == 0) lse[tok * H + P.h] = m + __logf(l);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
         doreg.load(d_o + tok * C + (size_t)P.h * HD, g, qvalid);
         oreg.load(o + tok * C + (size_t)P.h * HD, g, qvalid);
         float delta = BReg<T, HD>::dot(doreg, oreg);
-        delta += __shfl_xor(delta, 32, 64);
+        delta = wave_halves<WaveAdd>(delta);
         const float lq = qvalid ? lse[tok * H + P.h] : 0.f;
 
         f32x16_t dq[HD / 32];

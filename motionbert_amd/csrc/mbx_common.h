@@ -67,16 +67,42 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
 }
 
 // ---------------------------------------------------------------- wave-level reductions (64 lanes)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// VALU-only reduction: four DPP butterfly steps inside each 16-lane row (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror), then row_bcast:15 / row_bcast:31 carry the row sums upward so that lane 63 holds the total, which
+// v_readlane broadcasts.  No ds_bpermute: measured on MI355X, ds_bpermute-based reductions returned a wrong sum for
+// about one wave per 10^6 when a second stream kept other kernels resident on the same CUs (tools/determinism_check.py).
+// Every lane of the wave must be active.
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+struct WaveAdd {
+    static __device__ __forceinline__ float op(float a, float b) { return a + b; }
+    static __device__ __forceinline__ float identity(float) { return 0.f; }
+};
+struct WaveMax {
+    static __device__ __forceinline__ float op(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float identity(float v) { return v; }
+};
+template <typename Op> __device__ __forceinline__ float wave_reduce(float v) {
+    v = Op::op(v, dpp_mov<0xB1>(v, v));    // quad_perm [1,0,3,2]
+    v = Op::op(v, dpp_mov<0x4E>(v, v));    // quad_perm [2,3,0,1]
+    v = Op::op(v, dpp_mov<0x141>(v, v));   // row_half_mirror
+    v = Op::op(v, dpp_mov<0x140>(v, v));   // row_mirror: every lane now holds its row's result
+    v = Op::op(v, dpp_mov<0x142, 0xa>(Op::identity(v), v));   // row_bcast:15 into rows 1 and 3
+    v = Op::op(v, dpp_mov<0x143, 0xc>(Op::identity(v), v));   // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// op(v[lane], v[lane ^ 32]) on every lane: v_permlane32_swap exchanges the upper half of its first operand with the
+// lower half of the second, so {v, v} becomes {lo, lo} and {hi, hi}.  Inline asm because the clang builtin of ROCm 7.2
+// returns the first register for both results (tools/probes/wave_reduce.hip); the s_nop covers the VALU-write hazard.
+template <typename Op> __device__ __forceinline__ float wave_halves(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return Op::op(a, b);
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce<WaveAdd>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce<WaveMax>(v); }
 
 // ---------------------------------------------------------------- activation math (fp32)
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }

@@ -267,3 +267,100 @@ def test_attention(ops, dt, mode, B, T, H, hd):
     floor = float(dq2[:, 2 * C:].float().norm()) if (T if mode == MODE_TEMPORAL else J) == 1 else 0.0
     for i, n in enumerate(['dq', 'dk', 'dv']):
         check(f'attn_bwd.{n}.{tag}', dq[:, i * C:(i + 1) * C], dq2[:, i * C:(i + 1) * C], 5e-5 if dt == torch.float32 else 2e-2, floor)
+
+
+# ---------------------------------------------------------------------------------------------- memory safety
+class Guarded:
+    """Output/workspace buffers carved out of a larger allocation with sentinel bands on both sides: a kernel
+    that stores outside the tensor it was handed (ragged last tile, rounded-up grid) trips `verify()`."""
+    BAND = 1 << 18   # elements on each side
+
+    def __init__(self):
+        self.items = []
+
+    def __call__(self, *shape, dtype=torch.float32):
+        n = 1
+        for s in shape:
+            n *= s
+        raw = torch.empty(n + 2 * self.BAND, dtype=torch.uint8 if dtype == torch.uint8 else dtype, device=DEV)
+        sentinel = 85 if dtype == torch.uint8 else 12345.0
+        raw.fill_(sentinel)
+        self.items.append((raw, n, sentinel))
+        return raw[self.BAND:self.BAND + n].view(*shape)
+
+    def verify(self, what):
+        torch.cuda.synchronize()
+        for raw, n, sentinel in self.items:
+            lo, hi = raw[:self.BAND], raw[self.BAND + n:]
+            assert bool((lo == sentinel).all()) and bool((hi == sentinel).all()), \
+                f'{what}: store outside a {n}-element {raw.dtype} buffer'
+        self.items.clear()
+
+
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('B,T', [(16, 243), (3, 50), (1, 1)])
+def test_no_kernel_stores_outside_its_buffers(ops, dt, B, T, monkeypatch):
+    """Every entry of the ABI at training shapes (ragged M: 16*243*17 = 66096 = 258*256 + 48) with guarded outputs
+    and guarded workspaces."""
+    J, C, H, HID, R = 17, 512, 8, 1024, 512
+    M = B * T * J
+    G = Guarded()
+    monkeypatch.setattr(ops, '_ws', lambda key, fn, *a, device=None: G(max(int(fn(*a)), 16), dtype=torch.uint8))
+    torch.manual_seed(B * 1000 + T)
+    f = lambda *s: torch.randn(*s, device=DEV) * 0.5
+    t = lambda *s: f(*s).to(dt)
+    tag = f'{tname(dt)}.B{B}T{T}'
+    # embedding
+    x, w, b, pos, temp = f(B, T, J, 3), f(C, 3), f(C), f(1, J, C), f(1, 243, 1, C)
+    ops.embed_fwd(x, w, b, pos, temp, G(M, C), B, T, J)
+    G.verify(f'embed_fwd {tag}')
+    ops.embed_bwd(f(M, C), x, w, G(C, 3), G(C), G(1, J, C), G(1, 243, 1, C), G(B, T, J, 3), B, T, J)
+    G.verify(f'embed_bwd {tag}')
+    # LayerNorm
+    xs, gam, bet = f(M, C), f(C), f(C)
+    mean, rstd = G(M), G(M)
+    ops.layernorm_fwd(xs, gam, bet, 1e-6, G(M, C, dtype=dt), mean, rstd)
+    G.verify(f'layernorm_fwd {tag}')
+    mean, rstd = xs.mean(1), 1.0 / (xs.var(1, unbiased=False) + 1e-6).sqrt()
+    for dx_t in (True, False):
+        ops.layernorm_bwd(t(M, C), xs, mean, rstd, gam, f(M, C), None, G(M, C), G(M, C, dtype=dt) if dx_t else None, G(C), G(C))
+        G.verify(f'layernorm_bwd {tag} dx_t={dx_t}')
+    # GEMMs at the shapes of the model
+    for N, K in [(3 * C, C), (C, C), (HID, C), (C, HID), (R, C)]:
+        a, wt, bias = t(M, K), t(N, K), f(N)
+        ops.gemm_nt(a, wt, bias, EPI_STORE, out_t=G(M, N, dtype=dt))
+        G.verify(f'gemm_nt store {tag} N{N} K{K}')
+        ops.gemm_nt(a, wt, bias, EPI_GELU, out_t=G(M, N, dtype=dt), out2_t=G(M, N, dtype=dt))
+        ops.gemm_nt(a, wt, bias, EPI_GELU, out_t=None, out2_t=G(M, N, dtype=dt))
+        G.verify(f'gemm_nt gelu {tag} N{N} K{K}')
+        ops.gemm_nt(a, wt, bias, EPI_RESID, resid=f(M, N), out_f=G(M, N))
+        ops.gemm_nt(a, wt, bias, EPI_TANH, out_f=G(M, N))
+        G.verify(f'gemm_nt resid/tanh {tag} N{N} K{K}')
+        ops.gemm_nt(a, wt, None, EPI_DGELU, out_t=G(M, N, dtype=dt), aux_t=t(M, N))
+        G.verify(f'gemm_nt dgelu {tag} N{N} K{K}')
+        ops.gemm_tn(t(M, N), a, G(N, K), G(N))
+        ops.gemm_tn(t(M, N), a, G(N, K), None)
+        G.verify(f'gemm_tn {tag} N{N} K{K}')
+    # attention
+    for mode in (MODE_SPATIAL, MODE_TEMPORAL):
+        qkv = t(M, 3 * C)
+        o, lse = G(M, C, dtype=dt), G(M, H)
+        ops.attn_fwd(qkv, o, lse, B, T, J, H, (C // H) ** -0.5, mode)
+        G.verify(f'attn_fwd {tag} mode{mode}')
+        ops.attn_bwd(qkv, o.clone(), t(M, C), lse.clone(), G(M, 3 * C, dtype=dt), B, T, J, H, (C // H) ** -0.5, mode)
+        G.verify(f'attn_bwd {tag} mode{mode}')
+    # fusion, tail
+    x_st, x_ts, fw, fb = f(M, C), f(M, C), f(2, 2 * C), f(2)
+    alpha = G(M, 2)
+    ops.fuse_fwd(x_st, x_ts, fw, fb, G(M, C), alpha)
+    G.verify(f'fuse_fwd {tag}')
+    ops.fuse_bwd(f(M, C), x_st, x_ts, alpha.clone(), fw, G(M, C), G(M, C), G(M, C, dtype=dt), G(M, C, dtype=dt), G(2, 2 * C), G(2))
+    G.verify(f'fuse_bwd {tag}')
+    ops.average(x_st, x_ts, G(M, C))
+    ops.average_bwd(f(M, C), G(M, C), G(M, C), G(M, C, dtype=dt), G(M, C, dtype=dt))
+    G.verify(f'average {tag}')
+    rep, hw, hb = torch.tanh(f(M, R)), f(3, R), f(3)
+    ops.head_fwd(rep, hw, hb, G(M, 3))
+    ops.head_bwd(f(M, 3), rep, hw, G(M, R, dtype=dt), G(3, R), G(3))
+    ops.tanh_bwd(f(M, R), rep, G(M, R, dtype=dt))
+    G.verify(f'tail {tag}')

@@ -275,3 +275,89 @@ def test_hipgraph_replay_matches_eager_and_is_faster():
         t_eager, t_graph = timeit(lambda: model(x2)), timeit(lambda: fast(x2))
     REPORT['hipgraph.B1T243'] = dict(eager_ms=t_eager, graph_ms=t_graph)
     assert t_graph < t_eager
+
+
+GENERIC = [
+    dict(dim_in=2, dim_out=3, dim_feat=128, dim_rep=64, depth=1, num_heads=4, mlp_ratio=2, num_joints=13, maxlen=40),
+    dict(dim_in=3, dim_out=5, dim_feat=64, dim_rep=128, depth=2, num_heads=2, mlp_ratio=4, num_joints=25, maxlen=50, qkv_bias=False),
+    dict(dim_in=3, dim_out=3, dim_feat=256, dim_rep=512, depth=1, num_heads=4, mlp_ratio=1, num_joints=17, maxlen=243, att_fuse=False),
+    dict(dim_in=4, dim_out=2, dim_feat=128, dim_rep=256, depth=1, num_heads=2, mlp_ratio=2, num_joints=32, maxlen=64, qk_scale=0.2),
+]
+
+
+@pytest.mark.parametrize('idx', range(len(GENERIC)))
+def test_generic_constructor_arguments(idx):
+    """Constructor arguments beyond the two shipped model sizes: other joint counts, input/output widths, head
+    dims 32/64, no qkv bias, plain-average fusion (att_fuse=False, DSTformer.py:351), explicit qk_scale."""
+    cfg = GENERIC[idx]
+    model = build_model(cfg, seed=3)
+    trained_like(model, 4)
+    model = model.to(DEV)
+    B, T, J = 3, min(37, cfg['maxlen']), cfg['num_joints']
+    g = torch.Generator().manual_seed(idx)
+    x = torch.rand(B, T, J, cfg['dim_in'], generator=g).to(DEV) * 2 - 1
+    cot = torch.randn(B, T, J, cfg['dim_out'], generator=g).to(DEV)
+    ref, gref = _mock_reference(model, x, cot)
+    model.precision = 'fp32'
+    out = model(x)
+    (out * cot).sum().backward()
+    e_out = rel_l2(out.detach().cpu().numpy(), ref.cpu().numpy())
+    e_all, e_worst, worst = grad_errors({n: p.grad.cpu().numpy() for n, p in model.named_parameters()},
+                                        {n: v.cpu().numpy() for n, v in gref.items()})
+    REPORT[f'generic.{idx}'] = dict(out=e_out, grad_global=e_all, worst_grad=e_worst, worst_name=worst)
+    assert e_out < TOL_FP32 and e_all < TOL_FP32 and e_worst < TOL_FP32, (e_out, e_all, worst, e_worst)
+    model.precision = 'bf16'
+    model.zero_grad()
+    out16 = model(x)
+    (out16 * cot).sum().backward()
+    assert rel_l2(out16.detach().cpu().numpy(), ref.cpu().numpy()) < 8e-2
+
+
+def test_full_size_properties():
+    """BASELINE.json full size ([64,243,17,3], full model, bf16) through size-independent properties:
+    determinism, independence of the clips of a batch, linearity of backward in the cotangent, additivity of the
+    parameter gradients over a split of the batch (what data parallelism relies on), zero cotangent -> zero grads."""
+    model = build_model(FULL, seed=0)
+    trained_like(model, 1)
+    model = model.to(DEV)
+    model.precision = 'bf16'
+    B, T = 64, 243
+    x = make_input(B, T, 17, 77).to(DEV)
+    cot = torch.randn(B, T, 17, 3, generator=torch.Generator().manual_seed(78)).to(DEV)
+
+    def fwd_bwd(xx, cc, scale=1.0):
+        model.zero_grad(set_to_none=True)
+        out = model(xx)
+        (out * (cc * scale)).sum().backward()
+        return out.detach(), torch.cat([p.grad.flatten() for p in model.parameters()])
+    out1, g1 = fwd_bwd(x, cot)
+    out2, g2 = fwd_bwd(x, cot)
+    assert torch.equal(out1, out2) and torch.equal(g1, g2), 'the path must be deterministic (no atomics anywhere)'
+    assert torch.isfinite(out1).all() and torch.isfinite(g1).all()
+    # clips are independent: a sub-batch gives the same rows (same kernels, same per-token arithmetic)
+    with torch.no_grad():
+        sub = model(x[5:9])
+    assert torch.equal(sub, out1[5:9])
+    # backward is linear in the cotangent (power-of-two scale: exact in floating point up to the bf16 roundings of
+    # intermediate gradients, which scale exactly too)
+    _, g4 = fwd_bwd(x, cot, scale=4.0)
+    assert torch.allclose(g4, 4.0 * g1, rtol=1e-5, atol=0)
+    # gradients add over a batch split (sum-reduced loss): different token counts -> different dW split counts
+    _, ga = fwd_bwd(x[:40], cot[:40])
+    _, gb = fwd_bwd(x[40:], cot[40:])
+    rel = float((ga + gb - g1).norm() / g1.norm())
+    REPORT['full_size.split_additivity'] = rel
+    assert rel < 2e-3, rel
+    _, g0 = fwd_bwd(x, torch.zeros_like(cot))
+    assert float(g0.abs().max()) == 0.0
+
+
+def test_empty_batch_and_max_length():
+    model = build_model(LITE, seed=0).to(DEV)
+    out = model(torch.zeros(0, 243, 17, 3, device=DEV))
+    assert out.shape == (0, 243, 17, 3)
+    out.sum().backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0 for p in model.parameters())
+    assert model.get_representation(torch.zeros(0, 5, 17, 3, device=DEV)).shape == (0, 5, 17, 512)
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 244, 17, 3, device=DEV))   # longer than the learned temporal embedding (maxlen)
