@@ -23,9 +23,47 @@ extern "C" int mbx_version(void) { return 100; }
 static inline int clamp_grid(size_t want, int cap) { return (int)(want < (size_t)cap ? (want ? want : 1) : (size_t)cap); }
 
 // ------------------------------------------------------------------------------------------------
-// colsum finalize: out[c] = sum_p part[p*stride + col0 + c]
-// block = 64 columns x 4 part-groups
+// colsum finalize: out[c] = sum_p part[p*stride + col0 + c], fixed summation order (deterministic).
+// Vector kernel: a lane owns 4 consecutive columns (one 16-B load per partial row); a block is CL column lanes x
+// PL = 256/CL part lanes, every part lane keeps four loads in flight, the part lanes are folded through LDS.
+// CL = 64 for wide outputs (weight-gradient tiles: few partial rows, 10^5..10^6 columns), CL = 16 for narrow ones
+// (LayerNorm dgamma/dbeta: 10^3 partial rows, 10^3 columns).  Columns >= split go to out1 (two outputs, one launch).
+// The scalar kernel below remains for outputs whose width or offset is not a multiple of 4.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <int CL>
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ part, int nparts, size_t stride, int ncols,
+                                                      float* __restrict__ out0, float* __restrict__ out1, int split) {
+    constexpr int PLW = 64 / CL, PL = 4 * PLW;
+    __shared__ float4 red[PL][CL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane % CL, pl = wave * PLW + lane / CL;
+    const int c = (blockIdx.x * CL + cl) * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (c < ncols) {
+        const float* p = part + c;
+        int i = pl;
+        for (; i + 3 * PL < nparts; i += 4 * PL) {
+            const float4 v0 = ld4(p + (size_t)i * stride), v1 = ld4(p + (size_t)(i + PL) * stride);
+            const float4 v2 = ld4(p + (size_t)(i + 2 * PL) * stride), v3 = ld4(p + (size_t)(i + 3 * PL) * stride);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; i < nparts; i += PL) a0 += ld4(p + (size_t)i * stride);
+    }
+    red[pl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (pl == 0 && c < ncols) {
+        float4 t = red[0][cl];
+#pragma unroll
+        for (int q = 1; q < PL; ++q) t += red[q][cl];
+        float* o = c < split ? out0 + c : out1 + (c - split);
+        if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+            *reinterpret_cast<float4*>(o) = t;
+        } else {
+            o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nparts, int stride, int col0,
                                                      int ncols, float* __restrict__ out) {
     __shared__ float red[4][64];
@@ -47,10 +85,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     __syncthreads();
     if (grp == 0 && c < ncols) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
-int mbx_launch_colsum(const float* part, int nparts, int stride, int col0, int ncols, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, part, nparts, stride, col0, ncols, out);
+// two outputs: columns [0, split) -> out0, [split, ncols) -> out1 (pass split = ncols, out1 = nullptr for one output)
+static int launch_colsum2(const float* part, int nparts, int stride, int col0, int ncols, float* out0, float* out1, int split,
+                          hipStream_t s) {
+    const bool vec = ncols % 4 == 0 && col0 % 4 == 0 && stride % 4 == 0 && split % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(part + col0) & 15) == 0;
+    if (!vec) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((split + 63) / 64), dim3(256), 0, s, part, nparts, stride, col0, split, out0);
+        if (ncols > split)
+            hipLaunchKernelGGL(colsum_kernel, dim3((ncols - split + 63) / 64), dim3(256), 0, s, part, nparts, stride, col0 + split,
+                               ncols - split, out1);
+    } else if (ncols / 4 >= 64 * 512) {
+        hipLaunchKernelGGL(colsum4_kernel<64>, dim3((ncols / 4 + 63) / 64), dim3(256), 0, s, part + col0, nparts, (size_t)stride, ncols,
+                           out0, out1, split);
+    } else {
+        hipLaunchKernelGGL(colsum4_kernel<16>, dim3((ncols / 4 + 15) / 16), dim3(256), 0, s, part + col0, nparts, (size_t)stride, ncols,
+                           out0, out1, split);
+    }
     MBX_LAUNCH_CHECK("colsum");
     return 0;
+}
+int mbx_launch_colsum(const float* part, int nparts, int stride, int col0, int ncols, float* out, hipStream_t s) {
+    return launch_colsum2(part, nparts, stride, col0, ncols, out, nullptr, ncols, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -231,9 +287,66 @@ static inline int vpl_for(int C) { return C <= 256 ? 1 : C <= 512 ? 2 : C <= 102
     }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm forward
+// LayerNorm forward / backward.  Both are HBM-bound row kernels (one wave per row).  To keep enough bytes in flight
+// a wave works on TWO rows per iteration and issues every load of both rows before the first use; FULL (C == VPL*256,
+// the model sizes 256/512/1024) drops the per-slot bounds tests that would otherwise split the load cluster.
+// The grid is sized so that all workgroups are resident at once (<= 4 x 256 CUs).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VPL>
+#define LN_BLOCKS 1024
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+    typedef float4 type;
+    static __device__ __forceinline__ void unpack(const float4& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+};
+template <> struct Raw4<bf16_t> {
+    typedef uint2 type;
+    static __device__ __forceinline__ void unpack(const uint2& r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    }
+};
+__device__ __forceinline__ void unpack4(const float4& r, float (&v)[4]) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+
+template <int VPL, bool FULL>
+__device__ __forceinline__ void ln_fwd_load(const float* __restrict__ x, int row, int C, int lane, float4 (&raw)[VPL]) {
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        raw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FULL || c < C) raw[k] = ld4(x + (size_t)row * C + c);
+    }
+}
+template <typename T, int VPL, bool FULL>
+__device__ __forceinline__ void ln_fwd_row(const float4 (&raw)[VPL], const float (&g)[VPL][4], const float (&bt)[VPL][4], float eps,
+                                           float invC, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                           int row, int C, int lane) {
+    float v[VPL][4];
+    float s = 0.f;
+    ROW_LOOP(k) {
+        unpack4(raw[k], v[k]);
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);     // slots past C hold zeros
+    }
+    const float mu = wave_sum(s) * invC;
+    float q = 0.f;
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (FULL || c < C) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[k][i] -= mu; q = fmaf(v[k][i], v[k][i], q); }
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (FULL || c < C) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = fmaf(v[k][i] * rs, g[k][i], bt[k][i]);
+            store4<T>(y + (size_t)row * C + c, o);
+        }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+template <typename T, int VPL, bool FULL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int C) {
@@ -241,50 +354,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     float g[VPL][4], bt[VPL][4];
     ROW_LOOP(k) {
         const int c = ROW_C(k);
-        if (c < C) { load4<float>(gamma + c, g[k]); load4<float>(beta + c, bt[k]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { g[k][i] = 0.f; bt[k][i] = 0.f; }
+        if (FULL || c < C) { load4<float>(gamma + c, g[k]); load4<float>(beta + c, bt[k]); }
     }
     const float invC = 1.0f / (float)C;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
-        float v[VPL][4];
-        float s = 0.f;
-        ROW_LOOP(k) {
-            const int c = ROW_C(k);
-            if (c < C) { load4<float>(x + (size_t)row * C + c, v[k]); s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]); }
-        }
-        const float mu = wave_sum(s) * invC;
-        float q = 0.f;
-        ROW_LOOP(k) {
-            const int c = ROW_C(k);
-            if (c < C) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { v[k][i] -= mu; q = fmaf(v[k][i], v[k][i], q); }
-            }
-        }
-        const float rs = 1.0f / sqrtf(wave_sum(q) * invC + eps);
-        ROW_LOOP(k) {
-            const int c = ROW_C(k);
-            if (c < C) {
-                float o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = fmaf(v[k][i] * rs, g[k][i], bt[k][i]);
-                store4<T>(y + (size_t)row * C + c, o);
-            }
-        }
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    const int step = gridDim.x * 4;
+    for (int row0 = blockIdx.x * 4 + (threadIdx.x >> 6); row0 < M; row0 += 2 * step) {
+        const int row1 = row0 + step;
+        float4 ra[VPL], rb[VPL];
+        ln_fwd_load<VPL, FULL>(x, row0, C, lane, ra);
+        if (row1 < M) ln_fwd_load<VPL, FULL>(x, row1, C, lane, rb);
+        ln_fwd_row<T, VPL, FULL>(ra, g, bt, eps, invC, y, mean, rstd, row0, C, lane);
+        if (row1 < M) ln_fwd_row<T, VPL, FULL>(rb, g, bt, eps, invC, y, mean, rstd, row1, C, lane);
     }
 }
+#define LN_FWD_LAUNCH(TT, FULLV)                                                                                             \
+    DISPATCH_VPL(vpl, hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL, FULLV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (TT*)y, \
+                                         mean, rstd, M, C))
 extern "C" int mbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
                                  float* rstd, int M, int C, int dtype, void* stream) {
     MBX_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
     MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "layernorm_fwd: bad shape M=%d C=%d", M, C);
-    const int grid = clamp_grid((M + 3) / 4, 256 * 8);
+    MBX_CHECK_ARG(dtype == MBX_BF16 || dtype == MBX_F32, "layernorm_fwd: unknown dtype %d", dtype);
+    const int grid = clamp_grid((M + 3) / 4, LN_BLOCKS);
+    const int vpl = vpl_for(C);
+    const bool full = vpl > 0 && C == vpl * 256;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MBX_BF16) {
-        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, VPL>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (bf16_t*)y, mean, rstd, M, C));
-    } else if (dtype == MBX_F32) {
-        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((ln_fwd_kernel<float, VPL>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (float*)y, mean, rstd, M, C));
+        if (full) { LN_FWD_LAUNCH(bf16_t, true); } else { LN_FWD_LAUNCH(bf16_t, false); }
     } else {
-        return mbx_set_error("layernorm_fwd: unknown dtype %d", dtype);
+        if (full) { LN_FWD_LAUNCH(float, true); } else { LN_FWD_LAUNCH(float, false); }
     }
     MBX_LAUNCH_CHECK("layernorm_fwd");
     return 0;
@@ -302,8 +402,72 @@ __device__ __forceinline__ void block_fold_store(const float* lds /*[4][n]*/, in
 // LayerNorm backward (+ residual-gradient add, + T copy for the next GEMM)
 // partial row layout: [dgamma C | dbeta C]
 // ------------------------------------------------------------------------------------------------
-#define LN_BWD_BLOCKS 2048
-template <typename T, int VPL>
+template <typename T, int VPL, bool FULL, bool RES>
+__device__ __forceinline__ void ln_bwd_load(const T* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ dres,
+                                            const float* __restrict__ mean, const float* __restrict__ rstd, int row, int C, int lane,
+                                            typename Raw4<T>::type (&rd)[VPL], float4 (&rx)[VPL], float4 (&rr)[VPL], float& mu,
+                                            float& rs) {
+    mu = mean[row];
+    rs = rstd[row];
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (FULL || c < C) {
+            const size_t o = (size_t)row * C + c;
+            rd[k] = *reinterpret_cast<const typename Raw4<T>::type*>(dy + o);
+            rx[k] = ld4(x + o);
+            if (RES) rr[k] = ld4(dres + o);
+        }
+    }
+}
+template <typename T, int VPL, bool FULL, bool RES>
+__device__ __forceinline__ void ln_bwd_row(const typename Raw4<T>::type (&rd)[VPL], const float4 (&rx)[VPL], const float4 (&rr)[VPL],
+                                           float mu, float rs, const float (&g)[VPL][4], float (&ag)[VPL][4], float (&ab)[VPL][4],
+                                           float invC, const float* __restrict__ extra, float* __restrict__ dx, T* __restrict__ dx_t,
+                                           int row, int C, int lane) {
+    float d[VPL][4], xh[VPL][4];
+    float s1 = 0.f, s2 = 0.f;
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (FULL || c < C) {
+            Raw4<T>::unpack(rd[k], d[k]);
+            unpack4(rx[k], xh[k]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xh[k][i] = (xh[k][i] - mu) * rs;
+                ag[k][i] = fmaf(d[k][i], xh[k][i], ag[k][i]);
+                ab[k][i] += d[k][i];
+                d[k][i] *= g[k][i];
+                s1 += d[k][i];
+                s2 = fmaf(d[k][i], xh[k][i], s2);
+            }
+        }
+    }
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+    ROW_LOOP(k) {
+        const int c = ROW_C(k);
+        if (FULL || c < C) {
+            float r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = rs * (d[k][i] - s1 - xh[k][i] * s2);
+            if (RES) {
+                float t[4];
+                unpack4(rr[k], t);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] += t[i];
+            }
+            if (extra) {
+                float t[4];
+                load4<float>(extra + (size_t)row * C + c, t);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] += t[i];
+            }
+            store4<float>(dx + (size_t)row * C + c, r);
+            if (dx_t) store4<T>(dx_t + (size_t)row * C + c, r);
+        }
+    }
+}
+template <typename T, int VPL, bool FULL, bool RES>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
@@ -316,83 +480,56 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const int c = ROW_C(k);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ag[k][i] = 0.f; ab[k][i] = 0.f; g[k][i] = 0.f; }
-        if (c < C) load4<float>(gamma + c, g[k]);
+        if (FULL || c < C) load4<float>(gamma + c, g[k]);
     }
     const float invC = 1.0f / (float)C;
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float d[VPL][4], xh[VPL][4];
-        float s1 = 0.f, s2 = 0.f;
-        ROW_LOOP(k) {
-            const int c = ROW_C(k);
-            if (c < C) {
-                load4<T>(dy + (size_t)row * C + c, d[k]);
-                load4<float>(x + (size_t)row * C + c, xh[k]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xh[k][i] = (xh[k][i] - mu) * rs;
-                    ag[k][i] = fmaf(d[k][i], xh[k][i], ag[k][i]);
-                    ab[k][i] += d[k][i];
-                    d[k][i] *= g[k][i];
-                    s1 += d[k][i];
-                    s2 = fmaf(d[k][i], xh[k][i], s2);
-                }
-            }
-        }
-        s1 = wave_sum(s1) * invC;
-        s2 = wave_sum(s2) * invC;
-        ROW_LOOP(k) {
-            const int c = ROW_C(k);
-            if (c < C) {
-                float r[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) r[i] = rs * (d[k][i] - s1 - xh[k][i] * s2);
-                if (dres) {
-                    float t[4];
-                    load4<float>(dres + (size_t)row * C + c, t);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] += t[i];
-                }
-                if (extra) {
-                    float t[4];
-                    load4<float>(extra + (size_t)row * C + c, t);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] += t[i];
-                }
-                store4<float>(dx + (size_t)row * C + c, r);
-                if (dx_t) store4<T>(dx_t + (size_t)row * C + c, r);
-            }
-        }
+    const int step = gridDim.x * 4;
+    for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += 2 * step) {
+        const int row1 = row0 + step;
+        typename Raw4<T>::type da[VPL], db[VPL];
+        float4 xa[VPL], xb[VPL], ra[VPL], rb[VPL];
+        float mua, rsa, mub, rsb;
+        ln_bwd_load<T, VPL, FULL, RES>(dy, x, dres, mean, rstd, row0, C, lane, da, xa, ra, mua, rsa);
+        if (row1 < M) ln_bwd_load<T, VPL, FULL, RES>(dy, x, dres, mean, rstd, row1, C, lane, db, xb, rb, mub, rsb);
+        ln_bwd_row<T, VPL, FULL, RES>(da, xa, ra, mua, rsa, g, ag, ab, invC, extra, dx, dx_t, row0, C, lane);
+        if (row1 < M) ln_bwd_row<T, VPL, FULL, RES>(db, xb, rb, mub, rsb, g, ag, ab, invC, extra, dx, dx_t, row1, C, lane);
     }
     float* mine = lds + (size_t)wave * 2 * C;
     ROW_LOOP(k) {
         const int c = ROW_C(k);
-        if (c < C) { store4<float>(mine + c, ag[k]); store4<float>(mine + C + c, ab[k]); }
+        if (FULL || c < C) { store4<float>(mine + c, ag[k]); store4<float>(mine + C + c, ab[k]); }
     }
     __syncthreads();
     block_fold_store(lds, 2 * C, part + (size_t)blockIdx.x * 2 * C);
 }
-extern "C" size_t mbx_layernorm_bwd_ws(int C) { return (size_t)LN_BWD_BLOCKS * 2 * C * sizeof(float); }
+#define LN_BWD_LAUNCH(TT, FULLV, RESV)                                                                                        \
+    DISPATCH_VPL(vpl, hipLaunchKernelGGL((ln_bwd_kernel<TT, VPL, FULLV, RESV>), dim3(grid), dim3(256), shm, s, (const TT*)dy, x, mean, \
+                                         rstd, gamma, dres, extra, dx, (TT*)dx_t, part, M, C))
+#define LN_BWD_LAUNCH_T(TT)                                                            \
+    if (full && dres) { LN_BWD_LAUNCH(TT, true, true); }                               \
+    else if (full) { LN_BWD_LAUNCH(TT, true, false); }                                 \
+    else if (dres) { LN_BWD_LAUNCH(TT, false, true); }                                 \
+    else { LN_BWD_LAUNCH(TT, false, false); }
+extern "C" size_t mbx_layernorm_bwd_ws(int C) { return (size_t)LN_BLOCKS * 2 * C * sizeof(float); }
 extern "C" int mbx_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* dres, const float* extra, float* dx, void* dx_t, float* dgamma, float* dbeta,
                                  int M, int C, int dtype, void* ws, void* stream) {
     MBX_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
     MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape M=%d C=%d", M, C);
-    const int grid = clamp_grid((M + 3) / 4, LN_BWD_BLOCKS);
+    MBX_CHECK_ARG(dtype == MBX_BF16 || dtype == MBX_F32, "layernorm_bwd: unknown dtype %d", dtype);
+    const int grid = clamp_grid((M + 3) / 4, LN_BLOCKS);
     const size_t shm = (size_t)4 * 2 * C * sizeof(float);
+    const int vpl = vpl_for(C);
+    const bool full = vpl > 0 && C == vpl * 256;
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)ws;
     if (dtype == MBX_BF16) {
-        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, VPL>), dim3(grid), dim3(256), shm, s, (const bf16_t*)dy, x, mean, rstd, gamma, dres, extra, dx, (bf16_t*)dx_t, part, M, C));
-    } else if (dtype == MBX_F32) {
-        DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((ln_bwd_kernel<float, VPL>), dim3(grid), dim3(256), shm, s, (const float*)dy, x, mean, rstd, gamma, dres, extra, dx, (float*)dx_t, part, M, C));
+        LN_BWD_LAUNCH_T(bf16_t)
     } else {
-        return mbx_set_error("layernorm_bwd: unknown dtype %d", dtype);
+        LN_BWD_LAUNCH_T(float)
     }
     MBX_LAUNCH_CHECK("layernorm_bwd");
-    if (mbx_launch_colsum(part, grid, 2 * C, 0, C, dgamma, s)) return 1;
-    if (mbx_launch_colsum(part, grid, 2 * C, C, C, dbeta, s)) return 1;
-    return 0;
+    return launch_colsum2(part, grid, 2 * C, 0, 2 * C, dgamma, dbeta, C, s);
 }
 
 // ------------------------------------------------------------------------------------------------
