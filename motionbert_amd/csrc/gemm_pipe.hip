@@ -229,6 +229,79 @@ static constexpr int Q_BM = 256, Q_BN = 256, Q_BK = 32;
 static constexpr int Q_A_BYTES = Q_BM * P_ROWB, Q_W_BYTES = Q_BN * P_ROWB, Q_STAGE = Q_A_BYTES + Q_W_BYTES;  // 32 KiB
 static constexpr int Q_NSTAGE = 4;
 
+// coalesced epilogue shared by the 256 x 256 kernels.  A wave owns 128 rows x (32 NTN) columns of the tile as
+// acc[tn][tm] (tn: 32-column block, tm: 32-row block; in the transposed MFMA orientation lane (i, g) holds
+// C[tm*32 + i][tn*32 + 8q + 4g + e] in acc[tn][tm][4q + e]).  Each pass stages one 32-row x 64-column fp32 tile in the
+// wave's private LDS area (8.5 KiB) and writes it out as complete 128/256-byte row segments.
+template <int EPI, int NTN>
+__device__ __forceinline__ void nt_epilogue(f32x16_t (&acc)[NTN][4], char* er, const float* __restrict__ bias,
+                                            bf16_t* __restrict__ out_t, bf16_t* __restrict__ out2_t, float* __restrict__ out_f,
+                                            const float* __restrict__ resid, const bf16_t* __restrict__ aux, int M, int N,
+                                            int row_base, int col_base, int lane) {
+    const int i = lane & 31, g = lane >> 5;
+    constexpr int EROW = 64 * 4 + 16;
+    const int ec = (lane & 15) * 4, erow0 = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < NTN / 2; ++h) {
+        const int n = col_base + h * 64 + ec;
+        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias && n < N) load4<float>(bias + n, bb);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(er + i * EROW + (tn * 32 + 8 * q + 4 * g) * 4) =
+                        make_float4(acc[2 * h + tn][tm][4 * q], acc[2 * h + tn][tm][4 * q + 1], acc[2 * h + tn][tm][4 * q + 2],
+                                    acc[2 * h + tn][tm][4 * q + 3]);
+#pragma unroll 4
+            for (int p = 0; p < 8; ++p) {
+                const int rl = p * 4 + erow0, m = row_base + tm * 32 + rl;
+                const float4 t4 = *reinterpret_cast<const float4*>(er + rl * EROW + ec * 4);
+                if (m < M && n < N) {
+                    float v[4] = {t4.x + bb[0], t4.y + bb[1], t4.z + bb[2], t4.w + bb[3]};
+                    const size_t o = (size_t)m * N + n;
+                    if (EPI == MBX_EPI_STORE) {
+                        store4<bf16_t>(out_t + o, v);
+                    } else if (EPI == MBX_EPI_GELU) {
+                        if (out_t) store4<bf16_t>(out_t + o, v);   // pre-activation is only needed for backward
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                        store4<bf16_t>(out2_t + o, v);
+                    } else if (EPI == MBX_EPI_RESID) {
+                        float r[4];
+                        load4<float>(resid + o, r);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r[e];
+                        store4<float>(out_f + o, v);
+                    } else if (EPI == MBX_EPI_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                        store4<float>(out_f + o, v);
+                    } else if (EPI == MBX_EPI_DGELU) {
+                        float u[4];
+                        load4<bf16_t>(aux + o, u);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(u[e]);
+                        store4<bf16_t>(out_t + o, v);
+                    }
+                }
+            }
+        }
+    }
+}
+// 8-wave layout: wave (wm, wn) = (wave >> 2, wave & 3) owns rows [128 wm, +128) x cols [64 wn, +64)
+template <int EPI>
+__device__ __forceinline__ void nt256_epilogue(f32x16_t (&acc)[2][4], char* smem, const float* __restrict__ bias,
+                                               bf16_t* __restrict__ out_t, bf16_t* __restrict__ out2_t, float* __restrict__ out_f,
+                                               const float* __restrict__ resid, const bf16_t* __restrict__ aux, int M, int N, int m0,
+                                               int n0, int wave, int lane) {
+    __builtin_amdgcn_s_barrier();   // every wave is done with the k-loop's LDS stages
+    nt_epilogue<EPI, 2>(acc, smem + wave * (32 * (64 * 4 + 16)), bias, out_t, out2_t, out_f, resid, aux, M, N,
+                        m0 + (wave >> 2) * 128, n0 + (wave & 3) * 64, lane);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pipe256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                  const float* __restrict__ bias, bf16_t* __restrict__ out_t,
@@ -302,56 +375,232 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pipe256_kernel(const bf16_t* _
     }
 #undef Q_ISSUE
 
-    // coalesced epilogue: four passes of a 32-row x 64-column staging tile per wave (8.5 KiB, 68 KiB per workgroup)
-    constexpr int EROW = 64 * 4 + 16;
-    __builtin_amdgcn_s_barrier();
-    char* er = smem + wave * (32 * EROW);
-    const int ec = (lane & 15) * 4, erow0 = lane >> 4;
-    const int n = n0 + wn * 64 + ec;
-    float bb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias && n < N) load4<float>(bias + n, bb);
+    nt256_epilogue<EPI>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane);
+}
+
+// ================================================================================================
+// gemm_nt_rs256: the same 256 x 256 tile / 8-wave layout, but the k-tiles travel HBM/L2 -> VGPR -> LDS
+// (global_load_dwordx4 + ds_write_b128) instead of through the LDS-DMA path, whose L2 -> LDS rate beside a
+// running MFMA loop was measured at ~20 B/clk/CU (tools/probes/mfma_dma.hip) and caps the DMA kernels' loop.
+// Three k-tiles are in flight in registers (48 VGPRs), tile kt+1 is written to the other LDS stage after
+// the MFMAs of tile kt, one barrier per k-tile, two LDS stages.
+// ================================================================================================
+static constexpr int S_SMEM = 8 * 32 * (64 * 4 + 16) > 2 * Q_STAGE ? 8 * 32 * (64 * 4 + 16) : 2 * Q_STAGE;   // epilogue staging needs 68 KiB
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_rs256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                               const float* __restrict__ bias, bf16_t* __restrict__ out_t,
+                                                               bf16_t* __restrict__ out2_t, float* __restrict__ out_f,
+                                                               const float* __restrict__ resid, const bf16_t* __restrict__ aux,
+                                                               int M, int N, int K, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = xcd_remap2(blockIdx.x, gridDim.x);
+    const int n0 = (lid % ntn) * Q_BN, m0 = (lid / ntn) * Q_BM;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // staging assignment = the DMA kernels' LDS image: wave w owns rows [32 w, 32 w + 32) of A and of W, lane l holds the
+    // 16-byte chunk that lands at byte 16 l of each 16-row block (source chunk un-swizzled on the global side)
+    const int lr = lane >> 2, lp = lane & 3;
+    const bf16_t* srcA[2];
+    const bf16_t* srcW[2];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(er + i * EROW + (tn * 32 + 8 * q + 4 * g) * 4) =
-                    make_float4(acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]);
-#pragma unroll 4
-        for (int p = 0; p < 8; ++p) {
-            const int rl = p * 4 + erow0, m = m0 + wm * 128 + tm * 32 + rl;
-            const float4 t4 = *reinterpret_cast<const float4*>(er + rl * EROW + ec * 4);
-            if (m < M && n < N) {
-                float v[4] = {t4.x + bb[0], t4.y + bb[1], t4.z + bb[2], t4.w + bb[3]};
-                const size_t o = (size_t)m * N + n;
-                if (EPI == MBX_EPI_STORE) {
-                    store4<bf16_t>(out_t + o, v);
-                } else if (EPI == MBX_EPI_GELU) {
-                    if (out_t) store4<bf16_t>(out_t + o, v);   // pre-activation is only needed for backward
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-                    store4<bf16_t>(out2_t + o, v);
-                } else if (EPI == MBX_EPI_RESID) {
-                    float r[4];
-                    load4<float>(resid + o, r);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += r[e];
-                    store4<float>(out_f + o, v);
-                } else if (EPI == MBX_EPI_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-                    store4<float>(out_f + o, v);
-                } else if (EPI == MBX_EPI_DGELU) {
-                    float u[4];
-                    load4<bf16_t>(aux + o, u);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(u[e]);
-                    store4<bf16_t>(out_t + o, v);
-                }
-            }
-        }
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + lr;
+        const int sw = (lp ^ ((row >> 2) & 3)) << 3;
+        srcA[q] = A + (size_t)min(m0 + row, M - 1) * K + sw;
+        srcW[q] = W + (size_t)min(n0 + row, N - 1) * K + sw;
     }
+    char* dst = smem + wave * 32 * P_ROWB + lane * 16;
+
+    f32x16_t acc[2][4];   // [tn][tm]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / Q_BK;
+    typedef unsigned u32x4v_t __attribute__((ext_vector_type(4)));
+    u32x4v_t s0a, s0b, s0c, s0d, s1a, s1b, s1c, s1d, s2a, s2b, s2c, s2d;   // three register slots x (A0, A1, W0, W1)
+    // the loads are issued through inline asm so that the compiler's waitcnt pass does not see them: it would wait for
+    // ALL outstanding loads (vmcnt(0)) before the first ds_write of a slot, which serialises the prefetch; the counted
+    // waits below (loads return in order, no stores in the loop) keep the two newest tiles in flight instead.
+#define S_LD1(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
+#define S_LOAD(kt_, a_, b_, c_, d_)                                         \
+    do {                                                                    \
+        const size_t ko_ = (size_t)(kt_) * Q_BK;                            \
+        S_LD1(a_, srcA[0] + ko_);                                           \
+        S_LD1(b_, srcA[1] + ko_);                                           \
+        S_LD1(c_, srcW[0] + ko_);                                           \
+        S_LD1(d_, srcW[1] + ko_);                                           \
+    } while (0)
+#define S_WRITE(stage_, a_, b_, c_, d_)                                     \
+    do {                                                                    \
+        char* d0_ = dst + (stage_) * Q_STAGE;                               \
+        *reinterpret_cast<u32x4v_t*>(d0_) = a_;                             \
+        *reinterpret_cast<u32x4v_t*>(d0_ + 1024) = b_;                      \
+        *reinterpret_cast<u32x4v_t*>(d0_ + Q_A_BYTES) = c_;                 \
+        *reinterpret_cast<u32x4v_t*>(d0_ + Q_A_BYTES + 1024) = d_;          \
+    } while (0)
+    const int i = lane & 31, g = lane >> 5;
+#define S_COMPUTE(stage_)                                                                                                    \
+    do {                                                                                                                     \
+        const char* sA = smem + (stage_) * Q_STAGE;                                                                          \
+        const char* sW = sA + Q_A_BYTES;                                                                                     \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                   \
+            bf16x8_t fw[2], fa[4];                                                                                           \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
+                fw[t] = *reinterpret_cast<const bf16x8_t*>(sW + sw_off(wn * 64 + t * 32 + i, 2 * s_ + g));                   \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                    \
+                fa[t] = *reinterpret_cast<const bf16x8_t*>(sA + sw_off(wm * 128 + t * 32 + i, 2 * s_ + g));                  \
+            _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                                                 \
+                _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                                             \
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);             \
+        }                                                                                                                    \
+    } while (0)
+    // one k-tile: tile kt_ is in LDS stage kt_ & 1; slot CUR (this tile's old registers) is free for tile kt_ + 3,
+    // slot NXT holds tile kt_ + 1 and goes to the other stage after the MFMAs
+#define S_ITER(kt_, ca_, cb_, cc_, cd_, na_, nb_, nc_, nd_)                                                \
+    do {                                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        if ((kt_) + 3 < nk) S_LOAD((kt_) + 3, ca_, cb_, cc_, cd_);                                         \
+        S_COMPUTE((kt_) & 1);                                                                              \
+        if ((kt_) + 1 < nk) {                                                                              \
+            if ((kt_) + 3 < nk) WAIT_VMCNT(8); else if ((kt_) + 2 < nk) WAIT_VMCNT(4); else WAIT_VMCNT(0); \
+            S_WRITE(((kt_) + 1) & 1, na_, nb_, nc_, nd_);                                                  \
+        }                                                                                                  \
+    } while (0)
+
+    S_LOAD(0, s0a, s0b, s0c, s0d);
+    if (nk > 1) S_LOAD(1, s1a, s1b, s1c, s1d);
+    if (nk > 2) S_LOAD(2, s2a, s2b, s2c, s2d);
+    if (nk > 2) WAIT_VMCNT(8); else if (nk > 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);
+    S_WRITE(0, s0a, s0b, s0c, s0d);
+    for (int kt = 0; kt < nk; kt += 3) {
+        S_ITER(kt, s0a, s0b, s0c, s0d, s1a, s1b, s1c, s1d);
+        if (kt + 1 < nk) S_ITER(kt + 1, s1a, s1b, s1c, s1d, s2a, s2b, s2c, s2d);
+        if (kt + 2 < nk) S_ITER(kt + 2, s2a, s2b, s2c, s2d, s0a, s0b, s0c, s0d);
+    }
+#undef S_ITER
+#undef S_COMPUTE
+#undef S_WRITE
+#undef S_LOAD
+#undef S_LD1
+    nt256_epilogue<EPI>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane);
+}
+
+// ================================================================================================
+// gemm_nt_w4: 256 x 256 tile, FOUR waves (one per SIMD, up to 512 registers each) as 2 (M) x 2 (N), each wave
+// 128 x 128 = 4 x 4 MFMA tiles (256 accumulator registers).  Why: the 8-wave kernels read 96 KiB of fragments out
+// of LDS per 32-deep k-tile and the DMA writes 32 KiB into it -- 1024 clk of the 128 B/clk LDS port against 1031 clk
+// of MFMA work, i.e. the loop is LDS-bandwidth-bound (the register-staged variant above, which bypasses the DMA
+// path, runs at the same speed).  With 128 x 128 per wave a k-tile needs 8 fragment reads per 16 MFMAs instead of
+// 6 per 8: 64 + 32 = 96 KiB per k-tile, 75 % of the port at full MFMA rate.  One wave per SIMD has nobody to hide
+// its LDS latency behind, so the fragments are software-pipelined by hand: the reads of k-step s+1 are issued
+// before the 16 MFMAs of k-step s; the barrier that publishes the next k-tile sits between the two k-steps.
+// LDS-DMA ring of 4 stages x 32 KiB as in gemm_nt_pipe256 (each wave issues 8 DMA instructions per k-tile).
+// ================================================================================================
+template <int EPI, int NST>
+__global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ out_t,
+                                                            bf16_t* __restrict__ out2_t, float* __restrict__ out_f,
+                                                            const float* __restrict__ resid, const bf16_t* __restrict__ aux,
+                                                            int M, int N, int K, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // NST stages x 32 KiB (NST - 1 k-tiles in flight)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = xcd_remap2(blockIdx.x, gridDim.x);
+    const int n0 = (lid % ntn) * Q_BN, m0 = (lid / ntn) * Q_BM;
+    const int wm = wave >> 1, wn = wave & 1;   // wave tile: rows [128 wm, +128), cols [128 wn, +128)
+
+    // LDS-DMA: one instruction = 16 rows x 64 B; wave w fills rows [64 w, 64 w + 64) of A and of W (4 + 4 instr)
+    const int lr = lane >> 2, lp = lane & 3;
+    const bf16_t* srcA[4];
+    const bf16_t* srcW[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 64 + q * 16 + lr;
+        const int sw = (lp ^ ((row >> 2) & 3)) << 3;
+        srcA[q] = A + (size_t)min(m0 + row, M - 1) * K + sw;
+        srcW[q] = W + (size_t)min(n0 + row, N - 1) * K + sw;
+    }
+    char* dstA = smem + wave * 64 * P_ROWB;
+    char* dstW = smem + Q_A_BYTES + wave * 64 * P_ROWB;
+
+    f32x16_t acc[4][4];   // [tn][tm]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / Q_BK;
+#define W4_ISSUE(kt_, stage_)                                                          \
+    do {                                                                               \
+        const size_t ko_ = (size_t)(kt_) * Q_BK;                                       \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                             \
+            GLDS16(srcA[q_] + ko_, dstA + (stage_) * Q_STAGE + q_ * 1024);             \
+            GLDS16(srcW[q_] + ko_, dstW + (stage_) * Q_STAGE + q_ * 1024);             \
+        }                                                                              \
+    } while (0)
+    const int i = lane & 31, g = lane >> 5;
+    // fragment offsets inside a stage (k-step s adds chunk 2 s: the swizzle only touches chunk bits 0..1 -> xor 2 s... see below)
+    int offA[4], offW[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        offA[t] = sw_off(wm * 128 + t * 32 + i, g);
+        offW[t] = Q_A_BYTES + sw_off(wn * 128 + t * 32 + i, g);
+    }
+    // chunk index 2 s + g = (2 s) ^ g for g in {0, 1}; sw_off(row, c) = row * 64 + ((c ^ key) << 4) with key = (row >> 2) & 3, and
+    // (2 s + g) ^ key = (g ^ key) ^ (2 s)  ->  k-step 1 is the k-step-0 address with bit 5 (chunk bit 1) flipped
+#define W4_READ(buf_, stage_, s_)                                                                                \
+    do {                                                                                                         \
+        const char* st_ = smem + (stage_) * Q_STAGE;                                                             \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                          \
+            fa[buf_][t] = *reinterpret_cast<const bf16x8_t*>(st_ + (offA[t] ^ ((s_) << 5)));                    \
+            fw[buf_][t] = *reinterpret_cast<const bf16x8_t*>(st_ + (offW[t] ^ ((s_) << 5)));                    \
+        }                                                                                                        \
+    } while (0)
+#define W4_MMA(buf_)                                                                                             \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int tn = 0; tn < 4; ++tn)                                                         \
+            _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                                     \
+                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[buf_][tn], fa[buf_][tm], acc[tn][tm], 0, 0, 0); \
+    } while (0)
+
+    bf16x8_t fa[2][4], fw[2][4];
+    // The loop body is branch-free (one basic block: the compiler's lgkmcnt bookkeeping stays exact): past the end of K
+    // the DMA re-fetches the last k-tile into a stage nobody reads any more, so every wait is "one newer group in flight".
+    W4_ISSUE(0, 0);
+    W4_ISSUE(min(1, nk - 1), 1);
+    W4_ISSUE(min(2, nk - 1), 2);
+    if (NST == 5) { W4_ISSUE(min(3, nk - 1), 3); WAIT_VMCNT(24); } else { WAIT_VMCNT(16); }
+    __builtin_amdgcn_s_barrier();                      // tile 0 landed for everyone
+    W4_READ(0, 0, 0);
+    int stage = 0;
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        const int nstage = stage + 1 == NST ? 0 : stage + 1;
+        W4_READ(1, stage, 1);                          // fragments of k-step 1, in flight behind the MFMAs of k-step 0
+        W4_MMA(0);
+        if (NST == 5) WAIT_VMCNT(16); else WAIT_VMCNT(8);   // own DMA of tile kt+1 landed (NST - 3 newer groups may still fly)
+        __builtin_amdgcn_s_barrier();                  // ... for everyone; everyone is past tile kt-1 -> its stage is free
+        W4_ISSUE(min(kt + NST - 1, nk - 1), (stage + NST - 1) % NST);
+        W4_READ(0, nstage, 0);                         // first fragments of the next tile, behind the MFMAs of k-step 1
+        W4_MMA(1);
+        stage = nstage;
+    }
+    W4_READ(1, stage, 1);
+    W4_MMA(0);
+    W4_MMA(1);
+#undef W4_MMA
+#undef W4_READ
+#undef W4_ISSUE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // incl. the re-fetched tail tiles: the epilogue reuses the stages
+    __builtin_amdgcn_s_barrier();   // every wave is done with the k-loop's LDS stages
+    nt_epilogue<EPI, 4>(acc, smem + wave * (32 * (64 * 4 + 16)), bias, out_t, out2_t, out_f, resid, aux, M, N, m0 + wm * 128,
+                        n0 + wn * 128, lane);
 }
 
 // ================================================================================================
@@ -561,6 +810,54 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
                         const float* resid, const void* aux, int M, int N, int K, hipStream_t s) {
     const int ntn = (N + Q_BN - 1) / Q_BN, ntm = (M + Q_BM - 1) / Q_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
+    static const int w4 = [] { const char* e = getenv("MBX_NT_W4"); return e ? atoi(e) : 0; }();
+    if (w4) {
+        const size_t shm_w4 = (size_t)(w4 == 5 ? 5 : 4) * Q_STAGE;
+#define MBX_W_CASE(E)                                                                                             \
+    case E:                                                                                                       \
+        if (w4 == 5) {                                                                                            \
+            if (set_lds_attr(gemm_nt_w4_kernel<E, 5>, shm_w4, "gemm_nt_w4")) return 1;                            \
+            hipLaunchKernelGGL((gemm_nt_w4_kernel<E, 5>), grid, dim3(256), shm_w4, s, (const bf16_t*)a, (const bf16_t*)w, bias, \
+                               (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn);  \
+        } else {                                                                                                  \
+            if (set_lds_attr(gemm_nt_w4_kernel<E, 4>, shm_w4, "gemm_nt_w4")) return 1;                            \
+            hipLaunchKernelGGL((gemm_nt_w4_kernel<E, 4>), grid, dim3(256), shm_w4, s, (const bf16_t*)a, (const bf16_t*)w, bias, \
+                               (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn);  \
+        }                                                                                                         \
+        break;
+        switch (epi) {
+            MBX_W_CASE(MBX_EPI_STORE)
+            MBX_W_CASE(MBX_EPI_GELU)
+            MBX_W_CASE(MBX_EPI_RESID)
+            MBX_W_CASE(MBX_EPI_TANH)
+            MBX_W_CASE(MBX_EPI_DGELU)
+            default: return mbx_set_error("gemm_nt: unknown epilogue %d", epi);
+        }
+#undef MBX_W_CASE
+        MBX_LAUNCH_CHECK("gemm_nt_w4");
+        return 0;
+    }
+    static const int rs = [] { const char* e = getenv("MBX_NT_RS"); return e ? atoi(e) : 0; }();
+    if (rs) {
+        const size_t shm_rs = S_SMEM;
+#define MBX_S_CASE(E)                                                                                               \
+    case E:                                                                                                         \
+        if (set_lds_attr(gemm_nt_rs256_kernel<E>, shm_rs, "gemm_nt_rs256")) return 1;                               \
+        hipLaunchKernelGGL((gemm_nt_rs256_kernel<E>), grid, block, shm_rs, s, (const bf16_t*)a, (const bf16_t*)w, bias, \
+                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn);        \
+        break;
+        switch (epi) {
+            MBX_S_CASE(MBX_EPI_STORE)
+            MBX_S_CASE(MBX_EPI_GELU)
+            MBX_S_CASE(MBX_EPI_RESID)
+            MBX_S_CASE(MBX_EPI_TANH)
+            MBX_S_CASE(MBX_EPI_DGELU)
+            default: return mbx_set_error("gemm_nt: unknown epilogue %d", epi);
+        }
+#undef MBX_S_CASE
+        MBX_LAUNCH_CHECK("gemm_nt_rs256");
+        return 0;
+    }
     const size_t shm = Q_NSTAGE * Q_STAGE;
 #define MBX_Q_CASE(E)                                                                                                 \
     case E:                                                                                                           \
