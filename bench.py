@@ -169,6 +169,28 @@ def cpu_baseline(cfg, T, budget_s=20.0):
                 sample=f'torch fp32 port (oracle/torch_ops.py) of the full model fwd+bwd, {what}, {cores} threads, CPU: {cpu}')
 
 
+def pmc_traffic_bytes(B, T, precision):
+    """HBM bytes per launch of the dominant kernel family from the committed PMC summary (separate rocprofv3 --pmc
+    passes of this very workload, corrected as the micro-architecture guide prescribes: FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE).  Counters cannot be read from inside the process, so the number is the profile's, not live: it is
+    reported only for the configuration the profile was taken on, otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_bench_v3.txt')
+    if not (os.path.exists(path) and B == 64 and T == 243 and precision == 'bf16'):
+        return None
+    tot, n = 0.0, 0
+    for line in open(path):
+        if 'gemm_nt_pipe' not in line:
+            continue
+        f = line.split()
+        try:     # columns from the right: L2hit% write_MB fetchx2 fetch_MB lds_conf% mfma_busy us n
+            write_mb, fetch2_mb, calls = float(f[-2]), float(f[-3]), int(f[-8])
+        except (ValueError, IndexError):
+            continue
+        tot += calls * (fetch2_mb + write_mb) * 1e6
+        n += calls
+    return round(tot / n) if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -258,7 +280,8 @@ def main():
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
         roof = dict(bound='mfma', kernel='mbx_gemm_nt -> gemm_nt_pipe256_kernel / gemm_nt_pipe_kernel (bf16 MFMA GEMM, all 162 launches of a step)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                    traffic=None, traffic_ref='profiles/r01_pmc_bench_v3.txt (FETCH_SIZE x2 + WRITE_SIZE per kernel)', launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
+                    traffic=pmc_traffic_bytes(B, T, args.precision), traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt kernels)',
+                    traffic_ref='profiles/r01_pmc_bench_v3.txt (rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + WRITE_SIZE, KB)', launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
                     flops_per_launch=d['flops'] / d['calls'], dominant_by_time=dom)
     flops_step = 3.0 * model_flops_fwd(FULL, T) * B
     out = {
