@@ -570,6 +570,27 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                 acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[buf_][tn], fa[buf_][tm], acc[tn][tm], 0, 0, 0); \
     } while (0)
 
+    // pin the instruction mix of the two halves of an iteration (the machine scheduler otherwise sinks the fragment
+    // reads of the next k-step to the end of the MFMA block, where their latency is exposed: one wave per SIMD)
+#define W4_SCHED_READS()                                                  \
+    do {                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                \
+        _Pragma("unroll") for (int z_ = 0; z_ < 8; ++z_) {                \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+        }                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                \
+    } while (0)
+#define W4_SCHED_READS_DMA()                                              \
+    do {                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                \
+        _Pragma("unroll") for (int z_ = 0; z_ < 8; ++z_) {                \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+        }                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                \
+    } while (0)
     bf16x8_t fa[2][4], fw[2][4];
     // The loop body is branch-free (one basic block: the compiler's lgkmcnt bookkeeping stays exact): past the end of K
     // the DMA re-fetches the last k-tile into a stage nobody reads any more, so every wait is "one newer group in flight".
@@ -584,17 +605,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
         const int nstage = stage + 1 == NST ? 0 : stage + 1;
         W4_READ(1, stage, 1);                          // fragments of k-step 1, in flight behind the MFMAs of k-step 0
         W4_MMA(0);
+        W4_SCHED_READS();                              // 2 MFMAs, then one fragment read per MFMA, then 6 MFMAs of slack
         if (NST == 5) WAIT_VMCNT(16); else WAIT_VMCNT(8);   // own DMA of tile kt+1 landed (NST - 3 newer groups may still fly)
         __builtin_amdgcn_s_barrier();                  // ... for everyone; everyone is past tile kt-1 -> its stage is free
         W4_ISSUE(min(kt + NST - 1, nk - 1), (stage + NST - 1) % NST);
         W4_READ(0, nstage, 0);                         // first fragments of the next tile, behind the MFMAs of k-step 1
         W4_MMA(1);
+        W4_SCHED_READS_DMA();                          // same, with one DMA issue beside every fragment read
         stage = nstage;
     }
     W4_READ(1, stage, 1);
     W4_MMA(0);
     W4_MMA(1);
 #undef W4_MMA
+#undef W4_SCHED_READS
+#undef W4_SCHED_READS_DMA
 #undef W4_READ
 #undef W4_ISSUE
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // incl. the re-fetched tail tiles: the epilogue reuses the stages
