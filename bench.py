@@ -174,7 +174,7 @@ def pmc_traffic_bytes(B, T, precision):
     passes of this very workload, corrected as the micro-architecture guide prescribes: FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE).  Counters cannot be read from inside the process, so the number is the profile's, not live: it is
     reported only for the configuration the profile was taken on, otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_bench_v3.txt')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_bench_v6.txt')
     if not (os.path.exists(path) and B == 64 and T == 243 and precision == 'bf16'):
         return None
     tot, n = 0.0, 0
@@ -186,7 +186,7 @@ def pmc_traffic_bytes(B, T, precision):
             write_mb, fetch2_mb, calls = float(f[-2]), float(f[-3]), int(f[-8])
         except (ValueError, IndexError):
             continue
-        tot += calls * (fetch2_mb + write_mb) * 1e6
+        tot += calls * (fetch2_mb + write_mb) * 1048576    # table is in MiB (counter KB = 1024 B)
         n += calls
     return round(tot / n) if n else None
 
@@ -281,7 +281,7 @@ def main():
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
         roof = dict(bound='mfma', kernel='mbx_gemm_nt -> gemm_nt_pipe256_kernel / gemm_nt_pipe_kernel (bf16 MFMA GEMM, all 162 launches of a step)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                     traffic=pmc_traffic_bytes(B, T, args.precision), traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt kernels)',
-                    traffic_ref='profiles/r01_pmc_bench_v3.txt (rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + WRITE_SIZE, KB)', launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
+                    traffic_ref='profiles/r01_pmc_bench_v6.txt (rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + WRITE_SIZE, KB)', launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
                     flops_per_launch=d['flops'] / d['calls'], dominant_by_time=dom)
     flops_step = 3.0 * model_flops_fwd(FULL, T) * B
     out = {
