@@ -27,6 +27,16 @@
 // waves of a workgroup, which split the 32-row query (key) blocks between them.
 #include "mbx_common.h"
 
+// threads per workgroup: long sequences (K/V or Q/dO shared in LDS) use 8 waves -- one 32-row block each for T <= 256 --
+// so that the two workgroups a CU holds (72 KiB of LDS each) give every SIMD four waves to hide latency behind
+template <bool SHARED> struct AttnBlock { static constexpr int THREADS = SHARED ? 512 : 256, WAVES = THREADS / 64; };
+// the dK/dV kernel needs ~170 VGPRs (two 32x64 accumulators per lane besides the score fragments): eight waves per
+// workgroup would not raise its occupancy, and four waves with eight key blocks each measured faster
+#ifndef MBX_ATTN_KV_THREADS
+#define MBX_ATTN_KV_THREADS 256
+#endif
+template <bool SHARED> struct AttnBlockKV { static constexpr int THREADS = SHARED ? MBX_ATTN_KV_THREADS : 256, WAVES = THREADS / 64; };
+
 // ------------------------------------------------------------------------------------------------
 // per-type helpers
 // ------------------------------------------------------------------------------------------------
@@ -204,7 +214,7 @@ template <typename T> __host__ __device__ constexpr int rm_stride(int HD) { retu
 // is at most 8 fragments, but keeping only one fragment of scores live keeps the wave at ~100 VGPRs)
 // ================================================================================================
 template <typename T, int HD, bool SHARED>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+__global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) == 2) ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
                                                        int Tn, int J, int H, float scale, int mode, int nprob, int KP) {
     constexpr bool IS_BF = sizeof(T) == 2;
     constexpr int KSTR = rm_stride<T>(HD);
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const bool pvalid = prob < nprob;
     prob = min(prob, nprob - 1);
     const Prob P = decode_prob(prob, mode, Tn, J, H);
-    const int gtid = SHARED ? tid : lane, gsize = SHARED ? 256 : 64;
+    const int gtid = SHARED ? tid : lane, gsize = SHARED ? AttnBlock<SHARED>::THREADS : 64;
     char* kt = smem + (SHARED ? 0 : wave * (KBYTES + VBYTES));
     char* vt = kt + KBYTES;
     const size_t rstride = (size_t)P.tstep * C3;
@@ -227,7 +237,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     __syncthreads();
 
     const int nfr = (P.L + 31) / 32;
-    for (int qb = SHARED ? wave : 0; qb < nfr; qb += SHARED ? 4 : 1) {
+    const float c2 = scale * 1.44269504088896341f;
+    for (int qb = SHARED ? wave : 0; qb < nfr; qb += SHARED ? AttnBlock<SHARED>::WAVES : 1) {
         const int q = qb * 32 + (lane & 31);
         const bool qvalid = pvalid && q < P.L;
         const size_t tok = P.tok0 + (size_t)min(q, P.L - 1) * P.tstep;
@@ -238,30 +249,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         for (int df = 0; df < HD / 32; ++df)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[df][r] = 0.f;
-        float m = -INFINITY, l = 0.f;  // l: this lane's half of the row sum (lanes l, l^32 share a query)
+        // softmax in base 2: p = 2^(s*c2 - m2) with c2 = scale*log2(e) -- one fma + one v_exp_f32 per score; the max is
+        // taken over the raw scores (scale > 0) and only the tail fragment masks keys past L
+        float m2 = -INFINITY, l = 0.f;  // l: this lane's half of the row sum (lanes l, l^32 share a query)
         for (int f = 0; f < nfr; ++f) {
             f32x16_t s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
             MmaRows<T, HD>::run(kt, KSTR, 32 * f, qreg, lane, s);
-            float mx = -INFINITY;
+            if (32 * f + 32 > P.L) {   // wave-uniform: the last, partial fragment
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
-                s[r] = key < P.L ? s[r] * scale : -INFINITY;
-                mx = fmaxf(mx, s[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    s[r] = key < P.L ? s[r] : -INFINITY;
+                }
             }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
             mx = wave_halves<WaveMax>(mx);   // every fragment f < nfr holds >= 1 valid key: finite
-            const float mn = fmaxf(m, mx);
-            const float corr = __expf(m - mn);        // first fragment: exp(-inf) = 0
+            const float mn2 = fmaxf(m2, mx * c2);
+            const float corr = __builtin_amdgcn_exp2f(m2 - mn2);        // first fragment: 2^(-inf) = 0
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = __expf(s[r] - mn);
+                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mn2));
                 ps += s[r];
             }
             l = fmaf(l, corr, ps);
-            m = mn;
+            m2 = mn2;
 #pragma unroll
             for (int df = 0; df < HD / 32; ++df) {
 #pragma unroll
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         l = wave_halves<WaveAdd>(l);
         if (qvalid) {
             store_rowfrag<T, HD>(o + tok * C + (size_t)P.h * HD, oacc, 1.0f / l, g);
-            if (g == 0) lse[tok * H + P.h] = m + __logf(l);
+            if (g == 0) lse[tok * H + P.h] = (m2 + __builtin_amdgcn_logf(l)) * 0.69314718055994531f;   // natural-log units
         }
     }
 }
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 // backward, part 1: dQ   (lane = query)
 // ================================================================================================
 template <typename T, int HD, bool SHARED>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+__global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) == 2) ? 4 : 1) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                           const T* __restrict__ d_o, const float* __restrict__ lse,
                                                           T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
                                                           int nprob, int KP) {
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     const bool pvalid = prob < nprob;
     prob = min(prob, nprob - 1);
     const Prob P = decode_prob(prob, mode, Tn, J, H);
-    const int gtid = SHARED ? tid : lane, gsize = SHARED ? 256 : 64;
+    const int gtid = SHARED ? tid : lane, gsize = SHARED ? AttnBlock<SHARED>::THREADS : 64;
     char* kt = smem + (SHARED ? 0 : wave * per_prob);
     char* vt = kt + KP * RSTR;
     const size_t rstride = (size_t)P.tstep * C3;
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     __syncthreads();
 
     const int nfr = (P.L + 31) / 32;
-    for (int qb = SHARED ? wave : 0; qb < nfr; qb += SHARED ? 4 : 1) {
+    for (int qb = SHARED ? wave : 0; qb < nfr; qb += SHARED ? AttnBlock<SHARED>::WAVES : 1) {
         const int q = qb * 32 + (lane & 31);
         const bool qvalid = pvalid && q < P.L;
         const size_t tok = P.tok0 + (size_t)min(q, P.L - 1) * P.tstep;
@@ -314,7 +330,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
         oreg.load(o + tok * C + (size_t)P.h * HD, g, qvalid);
         float delta = BReg<T, HD>::dot(doreg, oreg);
         delta = wave_halves<WaveAdd>(delta);
-        const float lq = qvalid ? lse[tok * H + P.h] : 0.f;
+        // p = exp(s*scale - lse) = 2^(s*c2 - lse*log2 e): one fma + one v_exp_f32.  No masks: an invalid query lane is
+        // never stored, and a padded key has a zero K row (dS * K = 0) and a zero V row (dP = 0)
+        const float lq2 = qvalid ? lse[tok * H + P.h] * 1.44269504088896341f : 0.f;
+        const float c2 = scale * 1.44269504088896341f;
 
         f32x16_t dq[HD / 32];
 #pragma unroll
@@ -329,8 +348,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
             MmaRows<T, HD>::run(vt, RSTR, 32 * f, doreg, lane, dp);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
-                const float p = (qvalid && key < P.L) ? __expf(s[r] * scale - lq) : 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lq2));
                 s[r] = p * (dp[r] - delta) * scale;  // dS
             }
 #pragma unroll
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 // backward, part 2: dK, dV   (lane = key)
 // ================================================================================================
 template <typename T, int HD, bool SHARED>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+__global__ __launch_bounds__(AttnBlockKV<SHARED>::THREADS, SHARED ? 2 : 1) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                            const T* __restrict__ d_o, const float* __restrict__ lse,
                                                            T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
                                                            int nprob, int KP) {
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     const bool pvalid = prob < nprob;
     prob = min(prob, nprob - 1);
     const Prob P = decode_prob(prob, mode, Tn, J, H);
-    const int gtid = SHARED ? tid : lane, gsize = SHARED ? 256 : 64;
+    const int gtid = SHARED ? tid : lane, gsize = SHARED ? AttnBlockKV<SHARED>::THREADS : 64;
     char* qt = smem + (SHARED ? 0 : wave * per_prob);   // Q   [KP][hd]
     char* dot_ = qt + KP * RSTR;                          // dO  [KP][hd]
     float* lse_s = reinterpret_cast<float*>(dot_ + KP * RSTR);
@@ -385,14 +403,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
                 for (int d = 0; d < HD / 4; ++d)
                     dl = fmaf(x[d][0], y[d][0], fmaf(x[d][1], y[d][1], fmaf(x[d][2], y[d][2], fmaf(x[d][3], y[d][3], dl))));
             }
-            lse_s[q] = l;
+            lse_s[q] = l * 1.44269504088896341f;   // base-2 units: p = 2^(s*c2 - lse2)
             del_s[q] = dl;
         }
     }
     __syncthreads();
 
     const int nfr = (P.L + 31) / 32;
-    for (int kb = SHARED ? wave : 0; kb < nfr; kb += SHARED ? 4 : 1) {
+    const float c2 = scale * 1.44269504088896341f;
+    for (int kb = SHARED ? wave : 0; kb < nfr; kb += SHARED ? AttnBlockKV<SHARED>::WAVES : 1) {
         const int key = kb * 32 + (lane & 31);
         const bool kvalid = pvalid && key < P.L;
         const size_t tok = P.tok0 + (size_t)min(key, P.L - 1) * P.tstep;
@@ -419,7 +438,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;
-                    const float p = (kvalid && q0 + e < P.L) ? __expf(s[r] * scale - la[e]) : 0.f;
+                    // no masks: padded queries have zero Q and dO rows (dS^T Q = 0, P^T dO = 0), invalid key lanes are not stored
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -la[e]));
                     dp[r] = p * (dp[r] - da[e]) * scale;  // dS
                     s[r] = p;                              // P
                 }
@@ -590,7 +610,7 @@ static int launch_fwd(const void* qkv, void* o, float* lse, int Tn, int J, int H
     auto kern = attn_fwd_kernel<T, HD, SHARED>;
     if (set_lds(kern, shm, "attn_fwd")) return 1;
     const int grid = SHARED ? nprob : (nprob + 3) / 4;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, (const T*)qkv, (T*)o, lse, Tn, J, H, scale, mode, nprob, KP);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(AttnBlock<SHARED>::THREADS), shm, s, (const T*)qkv, (T*)o, lse, Tn, J, H, scale, mode, nprob, KP);
     MBX_LAUNCH_CHECK("attn_fwd");
     return 0;
 }
@@ -598,6 +618,7 @@ static int launch_fwd(const void* qkv, void* o, float* lse, int Tn, int J, int H
 extern "C" int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale, int mode,
                             int dtype, void* stream) {
     MBX_CHECK_ARG(qkv && o && lse, "attn_fwd: null pointer");
+    MBX_CHECK_ARG(scale > 0.f, "attn_fwd: scale must be positive (the running max is taken over the raw scores), got %g", (double)scale);
     if (check_attn_args("attn_fwd", B, T, J, H, hd, mode, dtype)) return 1;
     const int L = mode == MBX_ATTN_SPATIAL ? J : T;
     const int nprob = mode == MBX_ATTN_SPATIAL ? B * T * H : B * J * H;
@@ -624,9 +645,9 @@ static int launch_bwd(const void* qkv, const void* o, const void* d_o, const flo
     auto k2 = attn_bwd_dkv_kernel<T, HD, SHARED>;
     const size_t shm1 = SHARED ? per_dq : 4 * per_dq, shm2 = SHARED ? per_dkv : 4 * per_dkv;
     if (set_lds(k1, shm1, "attn_bwd_dq") || set_lds(k2, shm2, "attn_bwd_dkv")) return 1;
-    hipLaunchKernelGGL(k1, dim3(grid), dim3(256), shm1, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP);
+    hipLaunchKernelGGL(k1, dim3(grid), dim3(AttnBlock<SHARED>::THREADS), shm1, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP);
     MBX_LAUNCH_CHECK("attn_bwd_dq");
-    hipLaunchKernelGGL(k2, dim3(grid), dim3(256), shm2, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP);
+    hipLaunchKernelGGL(k2, dim3(grid), dim3(AttnBlockKV<SHARED>::THREADS), shm2, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP);
     MBX_LAUNCH_CHECK("attn_bwd_dkv");
     return 0;
 }
