@@ -265,6 +265,24 @@ def main():
     clips = B * world * args.steps / dt
     log(f'timed region: {ms:.2f} ms/step, {clips:.1f} clips/s')
 
+    # ---- BASELINE config 1 beside the headline: the same model and batch forward-only (eval, no_grad), rank 0 at N=1
+    fwd_only = None
+    if rank == 0 and world == 1:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                model(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                model(x)
+            torch.cuda.synchronize()
+        fdt = (time.perf_counter() - t1) / 5
+        model.train()
+        fwd_only = dict(value=round(B / fdt, 1), unit='clips/s', ms=round(fdt * 1e3, 2),
+                        tflops=round(model_flops_fwd(FULL, T) * B / fdt / 1e12, 1), sample='eval + no_grad, 5 timed passes after 2 warm-ups')
+        log(f'forward only: {fdt * 1e3:.2f} ms, {B / fdt:.1f} clips/s')
+
     # ---- one extra instrumented step (untimed): per-kernel HIP-event durations -> roofline of the dominant kernel
     roof, breakdown = None, None
     if rank == 0:
@@ -293,7 +311,7 @@ def main():
                    'global_batch': B * world, 'frames': T, 'parallelism': f'dp{world}'},
         'model_tflops': round(flops_step * world / (ms * 1e-3) / 1e12, 1),
         'model_mfma_frac': round(flops_step / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS), 4),
-        'roofline': roof, 'kernel_breakdown_ms': breakdown,
+        'roofline': roof, 'kernel_breakdown_ms': breakdown, 'forward_only': fwd_only,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
