@@ -39,3 +39,27 @@ def test_argument_errors_are_reported_not_crashed(lib):
     rc = lib.mbx_attn_fwd(1, 1, 1, 1, 4, 17, 8, 48, 0.1, 0, 1, None)
     assert rc != 0 and b'head dim' in lib.mbx_last_error()
     assert lib.mbx_gemm_tn_ws(4131, 1536, 512) > 0 and lib.mbx_layernorm_bwd_ws(512) > 0
+
+
+def test_no_lds_crossbar_permutes_in_device_code(lib, tmp_path):
+    """Regression guard for the concurrency finding in DESIGN.md: `ds_bpermute_b32`-based wave reductions returned
+    wrong sums when a second stream kept other kernels resident on the same CUs, so every cross-lane reduction in
+    libmbx.so is VALU-only (DPP / permlane).  Disassemble the gfx950 code objects of the built library and make
+    sure no LDS-crossbar permute slipped back in."""
+    import shutil
+    import subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not available')
+    from motionbert_amd import hip_ops
+    copy = tmp_path / 'libmbx.so'          # llvm-objdump writes the extracted bundles next to its input
+    shutil.copy(hip_ops.LIB_PATH, copy)
+    subprocess.run([objdump, '--offloading', str(copy)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [p for p in tmp_path.iterdir() if 'amdgcn' in p.name]
+    assert objs, 'no device code objects found in libmbx.so'
+    n_mfma = 0
+    for o in objs:
+        asm = subprocess.run([objdump, '-d', '--mcpu=gfx950', str(o)], check=True, capture_output=True, text=True).stdout
+        assert 'ds_bpermute' not in asm and 'ds_permute' not in asm and 'ds_swizzle' not in asm, f'{o.name}: LDS-crossbar permute found'
+        n_mfma += asm.count('v_mfma_f32_32x32x16_bf16')
+    assert n_mfma > 100, 'expected the bf16 MFMA kernels in the device code'
