@@ -212,11 +212,12 @@ def cpu_baseline(cfg, T, budget_s=20.0):
     value, what = _bounded_rate(run, cfg, T, 1, budget_s)
     return dict(value=round(value, 4), unit='clips/s', cores=cores, kind='port',
                 sample=f'torch fp32 port (oracle/torch_ops.py) of the full model fwd+bwd ({why_port}), {what}, {cores} threads, CPU: {_cpu_name()}; '
-                       'calibration: on the build container (8 vCPU, reference reachable) the port ran 0.463 clips/s against 0.512 for the '
-                       'unmodified reference on the same cores, i.e. the port is 0.90x the reference')
+                       'port vs unmodified reference on the same cores: tools/cpu_calibration.py, log in profiles/r03_cpu_calibration.txt')
 
 
-PMC_TABLE = os.path.join(ROOT, 'profiles', 'r02_pmc_bench.txt')
+PMC_TABLE = next((p for p in (os.path.join(ROOT, 'profiles', f'r0{r}_pmc_bench.txt') for r in (3, 2)) if os.path.exists(p)),
+                 os.path.join(ROOT, 'profiles', 'r03_pmc_bench.txt'))
+HBM_PEAK_TBS, HBM_ACHIEVABLE_TBS = 8.0, 6.3      # MI355X_MICROARCH.md: spec / measured float4 copy
 
 
 def pmc_traffic_bytes(B, T, precision):
@@ -548,11 +549,21 @@ def main():
         d = agg['gemm_nt']
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel='mbx_gemm_nt -> gemm_nt_pp256_kernel (store, GELU, dGELU epilogues) / gemm_nt_pipe_kernel (residual epilogue) (bf16 MFMA GEMM, all 162 launches of a step)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                    traffic=pmc_traffic_bytes(B, T, args.precision), traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt kernels)',
+        traffic = pmc_traffic_bytes(B, T, args.precision)
+        fpl, avg_s = d['flops'] / d['calls'], d['ms'] / d['calls'] * 1e-3
+        # which roof bounds the family: its arithmetic intensity (algorithmic FLOPs over the HBM bytes the counters saw) against
+        # the ridge peak / achievable-HBM (2500 TFLOP/s / 6.3 TB/s ~ 400 FLOP/B); without a counter table the label stays "mfma"
+        intensity = fpl / traffic if traffic else None
+        bound = 'hbm' if intensity is not None and intensity < peak / HBM_ACHIEVABLE_TBS else 'mfma'
+        hbm_tbs = traffic / avg_s / 1e12 if traffic else None
+        roof = dict(bound=bound, kernel='mbx_gemm_nt -> gemm_nt_pp256_kernel (store, GELU, dGELU epilogues) / gemm_nt_pipe_kernel (residual epilogue) (bf16 MFMA GEMM, all 162 launches of a step)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                    traffic=traffic, traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt kernels)',
                     traffic_source=('STATIC: ' + os.path.relpath(PMC_TABLE, ROOT) + ' (separate rocprofv3 --pmc passes of this command on this round\'s kernels: '
                                     'FETCH_SIZE x2 + WRITE_SIZE); not measured by this run') if os.path.exists(PMC_TABLE) else None, launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
-                    flops_per_launch=d['flops'] / d['calls'], dominant_by_time=dom)
+                    flops_per_launch=fpl, flop_per_hbm_byte=round(intensity, 1) if intensity else None,
+                    hbm_tb_s=round(hbm_tbs, 3) if hbm_tbs else None, hbm_frac=round(hbm_tbs / HBM_PEAK_TBS, 4) if hbm_tbs else None,
+                    hbm_frac_of_achievable=round(hbm_tbs / HBM_ACHIEVABLE_TBS, 4) if hbm_tbs else None,
+                    attainable_tflops=round(min(peak, intensity * HBM_ACHIEVABLE_TBS), 1) if intensity else None, dominant_by_time=dom)
     flops_step = 3.0 * model_flops_fwd(FULL, T) * B
     out = {
         'metric': 'clips/sec [B,243,17,3] DSTformer fwd+bwd', 'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world,

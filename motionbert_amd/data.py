@@ -154,10 +154,14 @@ class PackedMotion3D:
         for s in range(self.ring):
             free.put(s)
 
+        stop = threading.Event()
+
         def producer():                                   # ONE host thread: row gather from the page cache into pinned memory
             try:
                 for ch in chunks:
                     s = free.get()
+                    if s is None or stop.is_set():        # the consumer went away (break / exception): see the finally below
+                        return
                     srt = np.sort(ch)                     # ascending file offsets; the batch is a set, order inside it is irrelevant
                     np.take(self.label, srt, axis=0, out=slots[s][0].numpy()[:len(ch)])
                     if need_inp:
@@ -172,35 +176,50 @@ class PackedMotion3D:
         gen.manual_seed((seed * 1000003 + epoch) * 8191 + rank)
         copy_stream = torch.cuda.Stream(self.device) if cuda else None
         pending = None                                    # (slot, lab_dev, inp_dev, event) of the batch in flight
-        while True:
-            item = ready.get()
-            if isinstance(item, Exception):
-                raise item
-            nxt = None
-            if item is not None:
-                s, nb = item
-                if cuda:
-                    with torch.cuda.stream(copy_stream):
-                        lab = slots[s][0][:nb].to(self.device, non_blocking=True)
-                        inp = slots[s][1][:nb].to(self.device, non_blocking=True) if need_inp else None
-                        ev = torch.cuda.Event()
-                        ev.record(copy_stream)
+        try:
+            while True:
+                item = ready.get()
+                if isinstance(item, Exception):
+                    raise item
+                nxt = None
+                if item is not None:
+                    s, nb = item
+                    if cuda:
+                        with torch.cuda.stream(copy_stream):
+                            lab = slots[s][0][:nb].to(self.device, non_blocking=True)
+                            inp = slots[s][1][:nb].to(self.device, non_blocking=True) if need_inp else None
+                            ev = torch.cuda.Event()
+                            ev.record(copy_stream)
+                    else:
+                        lab = slots[s][0][:nb].clone()
+                        inp = slots[s][1][:nb].clone() if need_inp else None
+                        ev = None
+                    nxt = (s, lab, inp, ev)
+                if pending is not None:
+                    s0, lab0, inp0, ev0 = pending
+                    if ev0 is not None:
+                        torch.cuda.current_stream(self.device).wait_event(ev0)      # the copy finished before compute touches it ...
+                        ev0.synchronize()                                             # ... and before the host refills the pinned slot
+                        lab0.record_stream(torch.cuda.current_stream(self.device))
+                        if inp0 is not None:
+                            inp0.record_stream(torch.cuda.current_stream(self.device))
+                    free.put(s0)
+                    pending = nxt
+                    yield self._device_stage(inp0, lab0, gen)
                 else:
-                    lab = slots[s][0][:nb].clone()
-                    inp = slots[s][1][:nb].clone() if need_inp else None
-                    ev = None
-                nxt = (s, lab, inp, ev)
-            if pending is not None:
-                s0, lab0, inp0, ev0 = pending
-                if ev0 is not None:
-                    torch.cuda.current_stream(self.device).wait_event(ev0)      # the copy finished before compute touches it ...
-                    ev0.synchronize()                                             # ... and before the host refills the pinned slot
-                    lab0.record_stream(torch.cuda.current_stream(self.device))
-                    if inp0 is not None:
-                        inp0.record_stream(torch.cuda.current_stream(self.device))
-                free.put(s0)
-                yield self._device_stage(inp0, lab0, gen)
-            pending = nxt
-            if item is None:
-                break
-        th.join()
+                    pending = nxt
+                if item is None:
+                    break
+        finally:
+            # also reached when the consumer abandons the generator (break, exception in the training loop, GeneratorExit):
+            # release the loader thread -- it may sit in free.get() or in ready.put() on a full queue -- and the pinned slots
+            stop.set()
+            free.put(None)
+            while th.is_alive():
+                try:
+                    ready.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
+            if pending is not None and pending[3] is not None:
+                pending[3].synchronize()                   # an H2D copy still reading a pinned slot must finish before it is freed

@@ -82,6 +82,78 @@ def test_shards_are_disjoint_equal_and_cover_the_epoch(packed):
     assert n == 4
 
 
+def test_abandoned_epoch_releases_the_loader_thread(packed):
+    """a consumer that stops early (break / exception in the training loop) must not leave the producer thread
+    blocked on its queues with the pinned ring alive."""
+    import threading
+    import gc
+    prefix, _, _ = packed
+    ds = PackedMotion3D(prefix, device='cpu', train=False, ring=2)
+    before = threading.active_count()
+    for _ in range(3):
+        it = ds.batches(2, shuffle=False)
+        next(it)
+        it.close()                                   # GeneratorExit at the yield, as a `break` + garbage collection does
+        for k, _b in enumerate(ds.batches(2, shuffle=False)):
+            if k == 1:
+                break
+        gc.collect()
+    with pytest.raises(ZeroDivisionError):
+        for _b in ds.batches(2, shuffle=False):
+            1 / 0
+    gc.collect()
+    assert threading.active_count() == before
+    assert sum(b[0].shape[0] for b in ds.batches(4, shuffle=False)) == 13       # and the stream still works afterwards
+
+
+@pytest.mark.gpu
+def test_cuda_stream_delivers_the_stored_clips_bit_for_bit(tmp_path):
+    """the CUDA branch (copy stream, events, record_stream, pinned-slot reuse) value-checked: 64 known
+    clips, train=False, ring of 2 (so every slot is refilled several times per epoch), two epochs with different orders;
+    every delivered batch must equal the stored arrays bit for bit, with a compute kernel still reading the previous batch
+    when the next copy lands."""
+    n, T = 64, 243
+    rng = np.random.default_rng(5)
+    prefix = str(tmp_path / 'known')
+    arr = {}
+    for name in ('input', 'label'):
+        a = np.lib.format.open_memmap(f'{prefix}.{name}.npy', mode='w+', dtype=np.float32, shape=(n, T, 17, 3))
+        a[:] = rng.standard_normal((n, T, 17, 3)).astype(np.float32)
+        a[:, 0, 0, 0] = np.arange(n)                 # clip id in the first element
+        a.flush()
+        arr[name] = np.array(a)
+    import json
+    json.dump(dict(n=n, clip_shape=[T, 17, 3], has_input=True, split='test', subsets=['synthetic']), open(prefix + '.json', 'w'))
+    ds = PackedMotion3D(prefix, device='cuda', train=False, ring=2)
+    inp_d, lab_d = torch.from_numpy(arr['input']).cuda(), torch.from_numpy(arr['label']).cuda()
+    busy = torch.randn(4096, 4096, device='cuda')
+    for epoch in (0, 1):
+        seen, kept = [], []
+        for x, y in ds.batches(8, shuffle=True, epoch=epoch, seed=3):
+            assert x.is_cuda and y.is_cuda and x.shape == (8, T, 17, 3)
+            ids = x[:, 0, 0, 0].long()
+            busy = busy @ busy * 1e-4                # keep the compute stream busy: the copies must not race ahead of it
+            assert torch.equal(x, inp_d[ids]) and torch.equal(y, lab_d[ids])
+            kept.append((x, y, ids))                 # batches stay valid after their pinned slot has been reused
+            seen += ids.tolist()
+        assert sorted(seen) == list(range(n))
+        for x, y, ids in kept:
+            assert torch.equal(x, inp_d[ids]) and torch.equal(y, lab_d[ids])
+    first = [b[0][:, 0, 0, 0].tolist() for b in ds.batches(8, shuffle=True, epoch=0, seed=3)]
+    again = [b[0][:, 0, 0, 0].tolist() for b in ds.batches(8, shuffle=True, epoch=0, seed=3)]
+    other = [b[0][:, 0, 0, 0].tolist() for b in ds.batches(8, shuffle=True, epoch=1, seed=3)]
+    assert first == again and first != other
+    # early exit on the CUDA path: the loader thread and the pinned ring are released
+    import threading
+    before = threading.active_count()
+    for k, _b in enumerate(ds.batches(8, shuffle=False)):
+        if k == 2:
+            break
+    import gc
+    gc.collect()
+    assert threading.active_count() <= before
+
+
 @pytest.mark.gpu
 def test_pipeline_feeds_the_gpu_faster_than_the_backbone_consumes(tmp_path):
     """[N,243,17,3] clips at the benchmark batch (64): the stream must deliver well above the ~1,300 clips/s the forward pass

@@ -175,6 +175,21 @@ def test_head(ops, dt, M, R, D):
 
 
 @pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('numel', [64, 4131 * 1024, 1000 * 384 + 5])
+def test_gelu_fwd(ops, dt, numel):
+    """mbx_gelu_fwd (recompute mode rebuilds the MLP post-activation with it, engine._mlp_bwd) against the exact erf form
+    nn.GELU() computes (DSTformer.py:70), incl. a size that is no multiple of the vector width and the tails |u| > 6."""
+    u = rnd(numel, seed=11, dtype=dt, scale=2.0)
+    u[:8] = torch.tensor([-9.0, -6.0, -0.75, -0.0, 0.0, 0.75, 6.0, 9.0], device=DEV, dtype=dt)
+    g = torch.full((numel + 16,), 7.0, device=DEV, dtype=dt)      # guard band behind the output
+    ops.gelu_fwd(u, g[:numel])
+    ref = torch.nn.functional.gelu(u.float())
+    check(f'gelu_fwd.{tname(dt)}.{numel}', g[:numel], ref, TOL_T[dt])
+    assert float((g[:numel].float() - ref).abs().max()) < (2e-6 if dt == torch.float32 else 0.04)
+    assert bool((g[numel:] == 7.0).all()), 'gelu_fwd wrote past its output'
+
+
+@pytest.mark.parametrize('dt', TD)
 def test_prep_weights(ops, dt):
     P = {'a.weight': rnd(192, 64, seed=1), 'b.weight': rnd(64, 128, seed=2), 'c.weight': rnd(1536, 512, seed=3)}
     Wn, Wt = ops.prep_weights(P, ['a', 'b', 'c'], dt, True)

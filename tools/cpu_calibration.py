@@ -1,0 +1,33 @@
+"""CPU-baseline calibration: the unmodified reference DSTformer and the torch port (oracle/torch_ops.py driven by the product's
+sequencing) timed back to back on the SAME host cores with bench.cpu_baseline's own code and budget.  bench.py reports
+`cpu_baseline.kind = "port"` on hosts without a reference checkout (the GPU box); this script is where the ratio between
+the two comes from -- run it where /root/reference (or $MOTIONBERT_REFERENCE) exists and commit the log under profiles/.
+
+    python tools/cpu_calibration.py [--budget 20] > profiles/r03_cpu_calibration.txt
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--budget', type=float, default=20.0)
+    ap.add_argument('--frames', type=int, default=243)
+    args = ap.parse_args()
+    ref_dir = os.environ.get('MOTIONBERT_REFERENCE', '/root/reference')
+    ref = bench.cpu_baseline(bench.FULL, args.frames, args.budget)
+    os.environ['MOTIONBERT_REFERENCE'] = '/nonexistent'       # forces the port leg
+    port = bench.cpu_baseline(bench.FULL, args.frames, args.budget)
+    out = dict(reference=ref, port=port,
+               port_over_reference=round(port['value'] / ref['value'], 3) if ref['kind'] == 'reference' else None,
+               note=f'reference checkout: {ref_dir}; same process, same thread count, reference first')
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
