@@ -151,7 +151,9 @@ int mbx_tanh_bwd(const float* drep, const float* rep, void* dpre_t, size_t n, in
 size_t mbx_pose_loss_ws(int B, int T);
 int mbx_pose_loss(const float* pred, const float* gt, float lambda_scale, float lambda_velocity, float* losses, float* dpred,
                   float grad_scale, int B, int T, int J, void* ws, void* stream);
-/* AdamW (torch.optim.AdamW semantics, train.py:289) over ONE flat fp32 buffer of n parameters (n % 4 == 0), one launch.
+/* AdamW (torch.optim.AdamW semantics, train.py:289) over ONE flat fp32 buffer -- or one contiguous RANGE of it -- of n
+ * parameters, one launch.  p, g, m, v are parallel buffers: 4-byte aligned, same offset within a 16-byte line (a range that
+ * skips frozen parameters, learning.py:69-77 / train.py:284-289, need not start on a 16-byte boundary).
  * state[2] on the device = {step count, learning rate}; tick != 0 advances the step count first (once per optimizer step). */
 int mbx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float* state, float beta1, float beta2, float eps,
                    float weight_decay, int tick, void* stream);

@@ -101,34 +101,49 @@ extern "C" int mbx_pose_loss(const float* pred, const float* gt, float lambda_sc
 // the correct bias corrections, and a host-side LR schedule only has to rewrite state[1].
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void adamw_tick_kernel(float* state) { state[0] += 1.0f; }
+__device__ __forceinline__ void adamw_one(float& pv, float gv, float& mv, float& vv, float b1, float b2, float eps, float decay, float step,
+                                          float rs2) {
+    mv = fmaf(b1, mv, (1.0f - b1) * gv);
+    vv = fmaf(b2, vv, (1.0f - b2) * gv * gv);
+    pv = pv * decay - step * mv / (sqrtf(vv) * rs2 + eps);
+}
+// elements [0, head) and [head + 4 n4, n) one per thread (a range of the flat buffer need not start or end on a 16-byte
+// boundary: frozen parameters are skipped range by range), the aligned middle with 16-byte accesses
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, size_t n4, const float* __restrict__ state, float b1,
-                                                    float b2, float eps, float wd) {
+                                                    float* __restrict__ v, size_t n, size_t head, size_t n4, const float* __restrict__ state,
+                                                    float b1, float b2, float eps, float wd) {
     const float t = state[0], lr = state[1];
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
     const float step = lr / bc1, rs2 = rsqrtf(bc2), decay = 1.0f - lr * wd;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid < 8) {      // at most 3 leading + 3 trailing elements
+        const size_t i = tid < 4 ? tid : head + 4 * n4 + (tid - 4);
+        if ((tid < 4 && i < head) || (tid >= 4 && i < n)) adamw_one(p[i], g[i], m[i], v[i], b1, b2, eps, decay, step, rs2);
+    }
+    float* pa = p + head; const float* ga = g + head; float* ma = m + head; float* va = v + head;
+    for (size_t i = tid; i < n4; i += (size_t)gridDim.x * 256) {
         float pv[4], gv[4], mv[4], vv[4];
-        load4<float>(p + i * 4, pv); load4<float>(g + i * 4, gv); load4<float>(m + i * 4, mv); load4<float>(v + i * 4, vv);
+        load4<float>(pa + i * 4, pv); load4<float>(ga + i * 4, gv); load4<float>(ma + i * 4, mv); load4<float>(va + i * 4, vv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            mv[e] = fmaf(b1, mv[e], (1.0f - b1) * gv[e]);
-            vv[e] = fmaf(b2, vv[e], (1.0f - b2) * gv[e] * gv[e]);
-            pv[e] = pv[e] * decay - step * mv[e] / (sqrtf(vv[e]) * rs2 + eps);
-        }
-        store4<float>(p + i * 4, pv); store4<float>(m + i * 4, mv); store4<float>(v + i * 4, vv);
+        for (int e = 0; e < 4; ++e) adamw_one(pv[e], gv[e], mv[e], vv[e], b1, b2, eps, decay, step, rs2);
+        store4<float>(pa + i * 4, pv); store4<float>(ma + i * 4, mv); store4<float>(va + i * 4, vv);
     }
 }
 extern "C" int mbx_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float* state, float beta1, float beta2,
                               float eps, float weight_decay, int tick, void* stream) {
     MBX_CHECK_ARG(p && g && m && v && state, "adamw_step: null pointer");
-    MBX_CHECK_ARG(n % 4 == 0, "adamw_step: n %% 4 != 0 (pad the flat buffer)");
+    const size_t mis = (size_t)((uintptr_t)p & 15);
+    MBX_CHECK_ARG(mis % 4 == 0 && ((uintptr_t)g & 15) == mis && ((uintptr_t)m & 15) == mis && ((uintptr_t)v & 15) == mis,
+                  "adamw_step: p, g, m, v must be 4-byte aligned and share their offset within a 16-byte line (same range of parallel flat buffers)");
     hipStream_t s = (hipStream_t)stream;
     if (tick) hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, state);
     if (n) {
-        const size_t want = (n / 4 + 255) / 256;
-        const int grid = (int)(want < 256 * 16 ? want : 256 * 16);
-        hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n / 4, state, beta1, beta2, eps, weight_decay);
+        size_t head = ((16 - mis) % 16) / 4;
+        if (head > n) head = n;
+        const size_t n4 = (n - head) / 4;
+        const size_t want = (n4 + 255) / 256;
+        const int grid = (int)(want < 256 * 16 ? (want ? want : 1) : 256 * 16);
+        hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, head, n4, state, beta1, beta2, eps, weight_decay);
     }
     MBX_LAUNCH_CHECK("adamw_step");
     return 0;

@@ -67,24 +67,42 @@ def flat_layout(names, shapes, depth):
 
 
 class FlatAdamW(torch.optim.Optimizer):
-    """AdamW (torch.optim.AdamW semantics; reference train.py:289 `optim.AdamW(..., lr, weight_decay)`) for a
-    `motionbert_amd.DSTformer`: ONE kernel launch per step over one flat parameter buffer.
+    """AdamW (torch.optim.AdamW semantics; reference train.py:289 `optim.AdamW(..., lr, weight_decay)`) over ONE flat fp32
+    parameter buffer: one kernel launch per step for everything that has a gradient.
 
         opt = FlatAdamW(model, lr=2e-4, weight_decay=0.01)       # re-lays model parameters into one buffer (values kept)
         loss.backward(); opt.step(); opt.zero_grad()
         opt.lr = opt.lr * 0.99                                     # train.py:360-362: lr *= lr_decay each epoch
 
-    The gradients of one backward pass of the backbone already form one flat buffer in the same order; `step()` checks that
-    (data pointers) and otherwise -- frozen parameters, gradient accumulation from other sources -- packs them first."""
+    `model` is a `motionbert_amd.DSTformer` (flat layout = backward-completion order, the order in which the backbone's
+    backward writes its single flat gradient buffer: `step()` then uses that buffer as it is) or any other `nn.Module` /
+    list of `(name, parameter)` pairs (plain layout, gradients packed first -- e.g. the ActionNet head with its own
+    learning rate, MB_ft_NTU60_xsub.yaml:7-9).
+
+    Like torch.optim.AdamW, a parameter WITHOUT a gradient is skipped entirely -- no weight decay, no moment update: frozen
+    layers (`partial_train`, learning.py:69-77; the reference builds its optimizer over `requires_grad` parameters only,
+    train.py:284-289) and the backbone's unused `head.*` under `get_representation` keep their values bit for bit.  The
+    flat buffer is then updated range by range (one launch per contiguous run of parameters that have gradients)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, ops=None):
-        names, params = named_parameter_tensors(model)
+        if isinstance(model, torch.nn.Module):
+            names, params = named_parameter_tensors(model) if hasattr(model, '_param_names') else zip(*model.named_parameters())
+        else:
+            names, params = zip(*list(model))
         if not params or any(not p.is_cuda for p in params):
-            raise RuntimeError('FlatAdamW needs the model on a ROCm device (move it first: model.cuda())')
+            raise RuntimeError('FlatAdamW needs the parameters on a ROCm device (move the model first: model.cuda())')
         super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._names, self._params = list(names), list(params)
-        self._offs, total = flat_layout(names, [p.shape for p in params], model.depth)
-        self._n = (total + 3) // 4 * 4
+        self._backbone = isinstance(model, torch.nn.Module) and hasattr(model, '_param_names') and hasattr(model, 'depth')
+        if self._backbone:
+            self._offs, total = flat_layout(names, [p.shape for p in params], model.depth)
+        else:
+            self._offs, total = {}, 0
+            for n, p in zip(names, params):
+                self._offs[n] = (total, p.numel())
+                total += p.numel()
+        self._total, self._n = total, (total + 3) // 4 * 4
+        self._order = sorted(range(len(self._names)), key=lambda i: self._offs[self._names[i]][0])      # parameters in flat order
         dev = params[0].device
         self.flat = torch.zeros(self._n, dtype=torch.float32, device=dev)
         with torch.no_grad():
@@ -109,30 +127,46 @@ class FlatAdamW(torch.optim.Optimizer):
         for g in self.param_groups:
             g['lr'] = float(v)
 
+    def _active_ranges(self):
+        """[(lo, hi)] runs of the flat buffer covered by parameters that HAVE a gradient (merged when adjacent)."""
+        runs = []
+        for i in self._order:
+            if self._params[i].grad is None:
+                continue
+            o, k = self._offs[self._names[i]]
+            if runs and runs[-1][1] == o:
+                runs[-1][1] = o + k
+            else:
+                runs.append([o, o + k])
+        return [(a, b) for a, b in runs if b > a]
+
     def _flat_grad(self):
         """The gradients as one flat tensor in the optimizer's order.  One backward pass of the backbone hands every parameter
         a VIEW of a single flat buffer laid out exactly like `self.flat` (model._DSTformerFn.backward): then that buffer is
-        used as it is.  Anything else (frozen parameters, accumulated or foreign gradients) is packed into a scratch buffer."""
-        g0 = self._params[0].grad
-        if g0 is not None and g0.dtype == torch.float32:
-            st = g0.untyped_storage()
+        used as it is (parameters it did not differentiate -- `head.*` on the representation path -- have no gradient and are
+        not part of any range).  Anything else (accumulated or foreign gradients, another layout) is packed into a scratch buffer."""
+        first = next((self._params[i].grad for i in self._order if self._params[i].grad is not None), None)
+        if first is None:
+            return None
+        if self._backbone and first.dtype == torch.float32:
+            st = first.untyped_storage()
             ok = st.nbytes() >= 4 * self._n
             if ok:
                 for n, p in zip(self._names, self._params):
                     g = p.grad                       # (AccumulateGrad keeps the handed-over view, detached: same storage)
-                    if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.storage_offset() != self._offs[n][0]
+                    if g is None:
+                        continue
+                    if (g.dtype != torch.float32 or not g.is_contiguous() or g.storage_offset() != self._offs[n][0]
                             or g.untyped_storage().data_ptr() != st.data_ptr()):
                         ok = False
                         break
             if ok:
-                return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, 0, (self._n,), (1,))
+                return torch.empty(0, dtype=torch.float32, device=first.device).set_(st, 0, (self._n,), (1,))
         if self._gpack is None:
             self._gpack = torch.zeros_like(self.flat)
         for n, p in zip(self._names, self._params):
-            o, k = self._offs[n]
-            if p.grad is None:
-                self._gpack[o:o + k].zero_()
-            else:
+            if p.grad is not None:
+                o, k = self._offs[n]
                 self._gpack[o:o + k].copy_(p.grad.reshape(-1))
         return self._gpack
 
@@ -150,24 +184,65 @@ class FlatAdamW(torch.optim.Optimizer):
         if grp['lr'] != self._lr:              # someone (an LR scheduler) wrote param_groups directly
             self.lr = grp['lr']
         g = self._flat_grad()
+        if g is None:                          # nothing has a gradient: torch.optim.AdamW does nothing either (no step count)
+            return loss
+        runs = self._active_ranges()
+        if runs == [(0, self._total)]:
+            runs = [(0, self._n)]              # everything active: the padded buffer in one aligned launch
         with torch.cuda.device(self.flat.device):
-            ops.adamw_step(self.flat, g, self.exp_avg, self.exp_avg_sq, self.state_t, grp['betas'][0], grp['betas'][1], grp['eps'],
-                           grp['weight_decay'], tick=True)
+            for k, (lo, hi) in enumerate(runs):
+                ops.adamw_step(self.flat[lo:hi], g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.state_t, grp['betas'][0],
+                               grp['betas'][1], grp['eps'], grp['weight_decay'], tick=(k == 0))
         for p in self._params:                 # the kernel wrote through raw pointers: tell autograd the parameters changed
-            torch.autograd.graph.increment_version(p)
+            if p.grad is not None:
+                torch.autograd.graph.increment_version(p)
         return loss
 
+    # ---- checkpointing: torch.optim.AdamW's own format ({'state': {index: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}),
+    # parameter index = position in model.parameters() -- what the reference saves with `optimizer.state_dict()` (train.py:
+    # save_checkpoint) and reloads on resume, so its checkpoints load here and vice versa.  Tensors are copies.
     def state_dict(self):
-        return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, state=self.state_t, names=self._names,
-                    param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+        step = self.state_t[0].detach().clone()
+        state = {}
+        if float(step) > 0:
+            for i, (n, p) in enumerate(zip(self._names, self._params)):
+                o, k = self._offs[n]
+                state[i] = dict(step=step.clone().cpu(), exp_avg=self.exp_avg[o:o + k].view(p.shape).clone(),
+                                exp_avg_sq=self.exp_avg_sq[o:o + k].view(p.shape).clone())
+        # (the keys torch.optim.AdamW itself keeps in a group, so that the dict also loads into a torch optimizer)
+        grp = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=True)
+        grp.update({k: v for k, v in self.param_groups[0].items() if k != 'params'})
+        grp['lr'] = self._lr
+        grp['params'] = list(range(len(self._params)))
+        return dict(state=state, param_groups=[grp], names=list(self._names))
 
     def load_state_dict(self, sd):
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-        self.state_t.copy_(sd['state'])
-        self._lr = float(sd['state'][1])
-        for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
+        if 'state' not in sd or 'param_groups' not in sd:
+            raise KeyError("FlatAdamW.load_state_dict expects torch.optim.AdamW's format: {'state': {...}, 'param_groups': [...]}")
+        if 'names' in sd and list(sd['names']) != self._names:
+            raise ValueError('optimizer state was saved for a different parameter list (names differ)')
+        ids = [i for g in sd['param_groups'] for i in g['params']]
+        if len(ids) != len(self._params):
+            raise ValueError(f'optimizer state has {len(ids)} parameters, this model has {len(self._params)}')
+        pos = {pid: k for k, pid in enumerate(ids)}          # saved parameter id -> position in model.parameters()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        step = 0.0
+        for pid, st in sd['state'].items():
+            k = pos[int(pid)]
+            n, p = self._names[k], self._params[k]
+            if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                raise ValueError(f'optimizer state of {n}: shape {tuple(st["exp_avg"].shape)} != parameter {tuple(p.shape)}')
+            o, cnt = self._offs[n]
+            self.exp_avg[o:o + cnt].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + cnt].copy_(st['exp_avg_sq'].reshape(-1))
+            step = max(step, float(st['step']))
+        g0 = sd['param_groups'][0]
+        for k in ('betas', 'eps', 'weight_decay'):
+            if k in g0:
+                self.param_groups[0][k] = tuple(g0[k]) if k == 'betas' else g0[k]
+        self.state_t[0] = step
+        self.lr = float(g0.get('lr', self._lr))
 
 
 class GraphedTrainStep:
@@ -183,6 +258,11 @@ class GraphedTrainStep:
                  lambda_velocity: float = 20.0, warmup: int = 2):
         if not x.is_cuda:
             raise RuntimeError('GraphedTrainStep needs ROCm device tensors')
+        if any(r > 0 for r in getattr(model, 'drop_rates', ())):
+            # the dropout / DropPath base seed is a host integer drawn per forward (model.run) and passed to the kernels by value:
+            # a captured graph would replay ONE mask forever
+            raise NotImplementedError('GraphedTrainStep: dropout / DropPath rates > 0 are not supported under graph capture '
+                                      '(the mask seed would be baked into the graph); train eagerly or set the rates to 0')
         self.model, self.opt = model, optimizer
         self.ls, self.lv = float(lambda_scale), float(lambda_velocity)
         self.x, self.gt = x.detach().clone().contiguous().float(), gt.detach().clone().contiguous().float()

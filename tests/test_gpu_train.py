@@ -94,12 +94,114 @@ def test_flat_adamw_uses_the_backward_buffer_without_copy():
     m(make_input(1, 9, 17, 1).to(DEV)).sum().backward()
     g = opt._flat_grad()
     assert opt._gpack is None and g.data_ptr() == m.head.weight.grad.untyped_storage().data_ptr()
-    # frozen parameter -> packed path, still correct
+    # a frozen parameter has no gradient: the rest is still the backward's own buffer (no pack), and the range list skips it
     m.head.weight.requires_grad_(False)
     opt.zero_grad(set_to_none=True)
     m(make_input(1, 9, 17, 1).to(DEV)).sum().backward()
     g2 = opt._flat_grad()
-    assert opt._gpack is not None and float(g2[opt._offs['head.weight'][0]:][:10].abs().max()) == 0.0
+    o, k = opt._offs['head.weight']
+    assert opt._gpack is None and m.head.weight.grad is None
+    assert all(not (lo < o + k and o < hi) for lo, hi in opt._active_ranges()) and len(opt._active_ranges()) == 2
+
+
+def test_flat_adamw_skips_parameters_without_gradient():
+    """torch.optim.AdamW skips a parameter whose .grad is None -- no weight decay, no moment update.
+    Frozen layers (partial_train, learning.py:69-77; the reference's optimizer holds only requires_grad parameters,
+    train.py:284-289) and the backbone's unused head under get_representation() must stay bit-identical, and the trained
+    parameters must move exactly as under torch.optim.AdamW over the trainable subset."""
+    from motionbert_amd.train import FlatAdamW
+    a = build_model(LITE, seed=2).to(DEV)
+    b = build_model(LITE, seed=2).to(DEV)
+    for m in (a, b):
+        m.precision = 'fp32'
+        for n, p in m.named_parameters():      # freeze everything outside the last level, like partial_train_layers
+            p.requires_grad_(n.startswith(('blocks_st.4', 'blocks_ts.4', 'ts_attn.4', 'norm.', 'pre_logits', 'head')))
+    oa = FlatAdamW(a, lr=1e-3, weight_decay=0.1)
+    ob = torch.optim.AdamW([p for p in b.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.1)
+    before = {n: p.detach().clone() for n, p in a.named_parameters()}
+    x = make_input(2, 9, 17, 5).to(DEV)
+    for _ in range(3):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad(set_to_none=True)
+            m(x).square().sum().backward()
+            o.step()
+    moved = 0
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        o, k = oa._offs[n]
+        if not p.requires_grad:
+            assert torch.equal(p, before[n]), f'frozen parameter {n} changed (weight decay applied without a gradient)'
+            assert float(oa.exp_avg[o:o + k].abs().max()) == 0.0 and float(oa.exp_avg_sq[o:o + k].abs().max()) == 0.0, n
+        else:
+            moved += int(not torch.equal(p, before[n]))
+            assert float((p - q).abs().max()) <= 2 * 1e-3 * 3, n
+            if p.ndim >= 2 and not n.startswith('ts_attn'):
+                assert float((p - q).norm() / q.norm()) < 1e-4, (n, float((p - q).norm() / q.norm()))
+    assert moved > 20
+    # representation path: head.* gets no gradient (model.py hands back None, like the reference's autograd) -> untouched
+    c = build_model(LITE, seed=3).to(DEV)
+    oc = FlatAdamW(c, lr=1e-3, weight_decay=0.1)
+    hw, hb = c.head.weight.detach().clone(), c.head.bias.detach().clone()
+    c.get_representation(x).square().sum().backward()
+    oc.step()
+    assert torch.equal(c.head.weight, hw) and torch.equal(c.head.bias, hb) and float(oc.state_t[0]) == 1.0
+    # nothing has a gradient -> no step at all
+    oc.zero_grad(set_to_none=True)
+    oc.step()
+    assert float(oc.state_t[0]) == 1.0
+
+
+def test_flat_adamw_state_dict_is_torch_format():
+    """optimizer.state_dict() in the reference's checkpoints (train.py save_checkpoint / resume) is torch.optim.AdamW's
+    {'state', 'param_groups'}: a torch AdamW state loads into FlatAdamW and continues identically, FlatAdamW's own state
+    round-trips (copies, not live tensors) and a state for another model is refused."""
+    from motionbert_amd.train import FlatAdamW
+    a = build_model(LITE, seed=4).to(DEV)
+    b = build_model(LITE, seed=4).to(DEV)
+    for m in (a, b):
+        m.precision = 'fp32'
+    x = make_input(2, 9, 17, 6).to(DEV)
+    ob = torch.optim.AdamW(b.parameters(), lr=5e-4, weight_decay=0.01)
+    for _ in range(2):
+        ob.zero_grad(set_to_none=True)
+        b(x).square().sum().backward()
+        ob.step()
+    with torch.no_grad():
+        for p, q in zip(a.parameters(), b.parameters()):
+            p.copy_(q)
+    oa = FlatAdamW(a, lr=1e-3, weight_decay=0.5)
+    oa.load_state_dict(ob.state_dict())                     # torch format in
+    assert float(oa.state_t[0]) == 2.0 and oa.lr == 5e-4 and oa.param_groups[0]['weight_decay'] == 0.01
+    for m, o in ((a, oa), (b, ob)):
+        o.zero_grad(set_to_none=True)
+        m(x).square().sum().backward()
+        o.step()
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert float((p - q).abs().max()) <= 2 * 5e-4, n
+        if p.ndim >= 2 and not n.startswith('ts_attn'):
+            assert float((p - q).norm() / q.norm()) < 1e-5, n
+    sd = oa.state_dict()                                     # torch format out: loads into torch.optim.AdamW
+    assert set(sd) >= {'state', 'param_groups'} and len(sd['state']) == 260 and sd['param_groups'][0]['params'] == list(range(260))
+    ob2 = torch.optim.AdamW(b.parameters(), lr=1.0)
+    ob2.load_state_dict({k: v for k, v in sd.items() if k != 'names'})
+    assert ob2.param_groups[0]['lr'] == 5e-4 and float(ob2.state[next(iter(b.parameters()))]['step']) == 3.0
+    keep = sd['state'][5]['exp_avg'].clone()
+    oa.exp_avg.add_(1.0)
+    assert torch.equal(sd['state'][5]['exp_avg'], keep), 'state_dict() must return copies'
+    oa.load_state_dict(sd)
+    o5, k5 = oa._offs[oa._names[5]]
+    assert torch.equal(oa.exp_avg[o5:o5 + k5].view(keep.shape), keep)
+    other = FlatAdamW(build_model(dict(LITE, depth=2), seed=0).to(DEV), lr=1e-3)
+    with pytest.raises(ValueError):
+        other.load_state_dict(sd)
+    with pytest.raises(KeyError):
+        oa.load_state_dict(dict(exp_avg=oa.exp_avg))
+
+
+def test_graphed_train_step_refuses_dropout():
+    from motionbert_amd.train import FlatAdamW, GraphedTrainStep
+    m = build_model(dict(LITE, depth=1, drop_path_rate=0.1), seed=0).to(DEV)
+    with pytest.raises(NotImplementedError, match='dropout'):
+        GraphedTrainStep(m, FlatAdamW(m), make_input(1, 9, 17, 1).to(DEV), torch.zeros(1, 9, 17, 3, device=DEV))
 
 
 def test_graphed_train_step_matches_eager_steps():
