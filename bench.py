@@ -298,6 +298,63 @@ def bench_block(dev, B=256, T=243, iters=5):
                 target='fwd <= 7.55 ms (50 % of 2.5 PFLOP/s: 9.434 TFLOP per forward)', peak_hbm_gib=round(mem, 1))
 
 
+def _bench_augmenter():
+    """Augmenter2D with the reference's own parameter files (params/synthetic_noise.pth, params/d2c_params.pkl) as minted into
+    tests/golden/augment2d.npz, and the mask ratios of MB_pretrain.yaml:49-50."""
+    import numpy as np
+    from motionbert_amd.augment import Augmenter2D
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'augment2d.npz'))
+    d = z['d2c']
+    return Augmenter2D(noise=dict(mean=torch.from_numpy(z['noise_mean']), std=torch.from_numpy(z['noise_std']), weight=torch.from_numpy(z['noise_weight'])),
+                       d2c=dict(a=float(d[0]), b=float(d[1]), m=float(d[2]), s=float(d[3])), mask_ratio=0.05, mask_T_ratio=0.1)
+
+
+def make_pretrain(net, model, opt, B, J, rank, dev):
+    """BASELINE config 4 (MB_pretrain.yaml; train.py:155-206,325-330): one macro step = one PoseTrack-like 2D batch [B,30,17,3]
+    (has_gt: mask + noise, loss_2d_weighted), one InstaVariety-like 2D batch [B,81,17,3] (mask only), one 3D batch [B,243,17,3]
+    (mask + noise, pose losses) -- three optimizer steps, every piece on the device (motionbert_amd.train.PretrainStep)."""
+    from motionbert_amd.train import PretrainStep
+    step = PretrainStep(net, opt, aug=_bench_augmenter(), rootrel=True, mask=True, noise=True, lambda_scale=LAMBDA_SCALE, lambda_velocity=LAMBDA_VELOCITY)
+    x30, _ = make_batch(B, 30, J, 200 + rank, dev)
+    x81, _ = make_batch(B, 81, J, 300 + rank, dev)
+    x243, gt243 = make_batch(B, 243, J, 400 + rank, dev)
+
+    def macro():
+        step(x30, x30, has_3d=False, has_gt=True)
+        step(x81, x81, has_3d=False, has_gt=False)
+        return step(x243, gt243, has_3d=True, has_gt=True)
+    frames = B * (30 + 81 + 243)
+    flops = 3.0 * B * (model_flops_fwd(FULL, 30) + model_flops_fwd(FULL, 81) + model_flops_fwd(FULL, 243))
+    return macro, frames, flops
+
+
+def make_action(model, N, J, rank, dev, distributed):
+    """BASELINE config 5 (MB_ft_NTU60_xsub.yaml; train_action.py:143-149,172-188): ActionNet on [N=32, M=2, 243, 17, 3] (backbone
+    batch 64), head hidden_dim 2048 / 60 classes / dropout 0.5, cross-entropy, AdamW with lr_backbone 1e-4 and lr_head 1e-3."""
+    from motionbert_amd.action import ActionNet
+    from motionbert_amd.train import ActionStep
+    torch.manual_seed(1)
+    net = ActionNet(backbone=model, dim_rep=FULL['dim_rep'], num_classes=60, dropout_ratio=0.5, version='class', hidden_dim=2048,
+                    num_joints=J).to(dev).train()
+    step = ActionStep(net, lr_backbone=1e-4, lr_head=1e-3, weight_decay=0.01, distributed=distributed)
+    x, _ = make_batch(N * 2, 243, J, 500 + rank, dev)
+    x = x.reshape(N, 2, 243, J, 3)
+    labels = torch.randint(0, 60, (N,), generator=torch.Generator().manual_seed(600 + rank)).to(dev)
+    flops = 3.0 * 2 * N * model_flops_fwd(FULL, 243) + 3.0 * 2 * N * (J * FULL['dim_rep'] * 2048 + 2048 * 60)
+    return (lambda: step(x, labels)), step, flops
+
+
+def time_steps(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on
     127.0.0.1), exactly what `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` would do."""
@@ -332,6 +389,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the forward-only / Block B=256 / fp32-class side measurements')
     ap.add_argument('--block', action='store_true', help='only the north-star Block benchmark (B=256), printed as its own JSON line')
+    ap.add_argument('--workload', default='pose', choices=['pose', 'pretrain', 'action'],
+                    help="pose: BASELINE configs 2-3 (3D pose train step, the headline); pretrain: config 4 (masked / noisy 2D input, 2D + 3D "
+                         "batches of T = 30 / 81 / 243 alternating in lock-step across ranks); action: config 5 (ActionNet finetune, two LR groups)")
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' only for wiring tests)")
     args = ap.parse_args()
 
@@ -369,16 +429,33 @@ def main():
     # the training step of train.py:174-206 with its own pieces on the device too: fused pose loss +
     # gradient, one-launch AdamW over the flat parameter buffer (lr 2e-4, wd 0.01: MB_train_h36m.yaml:21-23)
     from motionbert_amd.train import FlatAdamW, GraphedTrainStep, pose_loss as fused_pose_loss
-    opt = FlatAdamW(model, lr=2e-4, weight_decay=0.01)
     B, T, J = args.batch, args.frames, FULL['num_joints']
     x, gt = make_batch(B, T, J, 100 + rank, dev)
+    wl_flops, wl_units, wl_text = None, B, None        # FLOPs and 243-frame-equivalent clips of one timed step on one rank
+    if args.workload == 'action':
+        step, action_step, wl_flops = make_action(model, B // 2, J, rank, dev, distributed=world > 1)
+        opt = action_step.opt_backbone
+        wl_text = (f'BASELINE config 5: ActionNet finetune step (MB_ft_NTU60_xsub.yaml): [{B // 2},2,243,17,3] per GPU -> backbone batch {B}, fused '
+                   'dropout(0.5) + mean over T and persons in the backbone tail, fc1 8704->2048 + BatchNorm1d + ReLU + fc2 -> 60 classes, cross-entropy, '
+                   'AdamW in two flat groups (lr_backbone 1e-4, lr_head 1e-3); fwd + bwd + both updates timed')
+    else:
+        opt = FlatAdamW(model, lr=2e-4 if args.workload == 'pose' else 5e-4, weight_decay=0.01)
+    if args.workload == 'pretrain':
+        step, frames, wl_flops = make_pretrain(net, model, opt, B, J, rank, dev)
+        wl_units = frames / 243.0
+        wl_text = (f'BASELINE config 4: pre-training macro step (MB_pretrain.yaml; train.py:155-206,325-330) = three optimizer steps per GPU in lock-step '
+                   f'across ranks: 2D batch [{B},30,17,3] (mask + synthetic noise, loss_2d_weighted), 2D batch [{B},81,17,3] (mask, loss_2d_weighted), 3D batch '
+                   f'[{B},243,17,3] (mask + noise, mpjpe + 0.5 n_mpjpe + 20 velocity); augmentation, losses and AdamW as device kernels; value counts '
+                   f'243-frame-equivalent clips ({frames} frames / 243 per macro step per GPU)')
 
-    def step():
+    def pose_step():
         opt.zero_grad(set_to_none=True)
         total, losses = fused_pose_loss(net(x), gt, LAMBDA_SCALE, LAMBDA_VELOCITY)
         total.backward()
         opt.step()
         return losses
+    if args.workload == 'pose':
+        step = pose_step
 
     def sync():
         if dist is not None:
@@ -402,12 +479,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
-    clips = B * world * args.steps / dt
+    clips = wl_units * world * args.steps / dt
     log(f'timed region: {ms:.2f} ms/step, {clips:.1f} clips/s')
 
     # ---- BASELINE config 1 beside the headline: the same model and batch forward-only (eval, no_grad), rank 0 at N=1
     fwd_only = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == 'pose':
         model.eval()
         with torch.no_grad():
             for _ in range(2):
@@ -426,7 +503,7 @@ def main():
     # ---- the mode that meets the north-star 1e-3 gate, with a throughput number beside the headline:
     # the same training step in the fp32-class precisions (same batch, same loss, same optimizer), a short timed sample
     gate_modes = None
-    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16':
+    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16' and args.workload == 'pose':
         gate_modes = {}
         for prec in ('bf16x3', 'fp32'):
             if prec not in M._DTYPES:
@@ -450,7 +527,7 @@ def main():
             torch.cuda.empty_cache()
         model.precision = args.precision
     block = None
-    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16':
+    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16' and args.workload == 'pose':
         torch.cuda.empty_cache()
         try:
             block = bench_block(dev)
@@ -462,7 +539,7 @@ def main():
     # ---- BASELINE config 3 (MB_train_h36m.yaml:10: batch 32): the step issued eagerly (~850 launches from Python) against the
     # same step replayed from one hipGraph (forward + loss + backward + AdamW captured once)
     cfg3 = None
-    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16':
+    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16' and args.workload == 'pose':
         try:
             x3, gt3 = make_batch(32, T, J, 7, dev)
 
@@ -502,7 +579,7 @@ def main():
     # ---- the north-star batch on the FULL model: 256 clips x 243 frames per GPU do not fit with every activation saved
     # (78 GiB at 64 clips -> ~312 GiB); the low-memory mode (model.recompute) rebuilds LayerNorm outputs and MLP post-activations
     full256 = None
-    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16':
+    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16' and args.workload == 'pose':
         try:
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats()
@@ -530,6 +607,39 @@ def main():
             full256 = dict(error=f'{type(e).__name__}: {e}'[:300])
         model.recompute = False
         opt.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE configs 4 and 5 at N = 1 beside the headline; `--workload pretrain|action` times them as
+    # the main step (and under --gpus N), these are short samples of the same step functions
+    cfg4 = cfg5 = None
+    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16' and args.workload == 'pose':
+        try:
+            macro, frames, fl4 = make_pretrain(model, model, opt, B, J, rank, dev)
+            d4 = time_steps(macro, 3, 2)
+            cfg4 = dict(workload=f'config 4 (MB_pretrain.yaml): macro step = 2D batch [{B},30,17,3] (mask + noise, loss_2d_weighted) + 2D batch [{B},81,17,3] '
+                                 f'(mask, loss_2d_weighted) + 3D batch [{B},243,17,3] (mask + noise, pose losses): three fwd + bwd + AdamW steps, augment2D / losses '
+                                 'as device kernels; 3 timed macro steps after 2 warm-ups',
+                        ms_per_macro_step=round(d4 * 1e3, 2), frames_per_s=round(frames / d4, 1), clips243_equiv_per_s=round(frames / 243.0 / d4, 1),
+                        model_tflops=round(fl4 / d4 / 1e12, 1))
+            log(f'config 4 (pretrain macro step): {d4 * 1e3:.1f} ms, {frames / 243.0 / d4:.1f} 243-frame-equivalent clips/s')
+            del macro
+        except Exception as e:
+            cfg4 = dict(error=f'{type(e).__name__}: {e}'[:300])
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        try:
+            torch.manual_seed(0)
+            m5 = DSTformer(norm_layer=partial(nn.LayerNorm, eps=1e-6), **FULL).to(dev)
+            m5.precision = args.precision
+            fn5, st5, fl5 = make_action(m5, 32, J, rank, dev, distributed=False)
+            d5 = time_steps(fn5, 3, 2)
+            cfg5 = dict(workload='config 5 (MB_ft_NTU60_xsub.yaml): ActionNet step on [32,2,243,17,3] (backbone batch 64), dropout 0.5 + means fused in the '
+                                 'backbone tail, head 8704->2048->60, cross-entropy, two flat AdamW groups (lr 1e-4 / 1e-3); 3 timed steps after 2 warm-ups',
+                        ms_per_step=round(d5 * 1e3, 2), samples_per_s=round(32 / d5, 1), clips_per_s=round(64 / d5, 1), model_tflops=round(fl5 / d5 / 1e12, 1))
+            log(f'config 5 (ActionNet step): {d5 * 1e3:.1f} ms, {64 / d5:.1f} clips/s')
+            del fn5, st5, m5
+        except Exception as e:
+            cfg5 = dict(error=f'{type(e).__name__}: {e}'[:300])
         torch.cuda.empty_cache()
 
     # ---- one extra instrumented step (untimed): per-kernel HIP-event durations -> roofline of the dominant kernel
@@ -564,17 +674,17 @@ def main():
                     hbm_tb_s=round(hbm_tbs, 3) if hbm_tbs else None, hbm_frac=round(hbm_tbs / HBM_PEAK_TBS, 4) if hbm_tbs else None,
                     hbm_frac_of_achievable=round(hbm_tbs / HBM_ACHIEVABLE_TBS, 4) if hbm_tbs else None,
                     attainable_tflops=round(min(peak, intensity * HBM_ACHIEVABLE_TBS), 1) if intensity else None, dominant_by_time=dom)
-    flops_step = 3.0 * model_flops_fwd(FULL, T) * B
+    flops_step = wl_flops if wl_flops is not None else 3.0 * model_flops_fwd(FULL, T) * B
     out = {
         'metric': 'clips/sec [B,243,17,3] DSTformer fwd+bwd', 'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-        'config': {'workload': f'MotionBERT full DSTformer (dim_feat 512, depth 5, 8 heads, mlp_ratio 2) train step: fwd + bwd + AdamW, '
+        'config': {'workload': wl_text if wl_text else f'MotionBERT full DSTformer (dim_feat 512, depth 5, 8 heads, mlp_ratio 2) train step: fwd + bwd + AdamW, '
                                f'{B} clips/GPU x T={T} x J={J}, random-init weights, pose loss (mpjpe + 0.5 n_mpjpe + 20 velocity, fused kernel), one-launch flat AdamW',
                    'global_batch': B * world, 'frames': T, 'parallelism': f'dp{world}'},
         'model_tflops': round(flops_step * world / (ms * 1e-3) / 1e12, 1),
         'model_mfma_frac': round(flops_step / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS), 4),
-        'roofline': roof, 'kernel_breakdown_ms': breakdown, 'forward_only': fwd_only, 'gate_1e-3_modes': gate_modes, 'block_b256': block, 'config3_b32': cfg3, 'full_model_b256': full256,
+        'roofline': roof, 'kernel_breakdown_ms': breakdown, 'forward_only': fwd_only, 'gate_1e-3_modes': gate_modes, 'block_b256': block, 'config3_b32': cfg3, 'full_model_b256': full256, 'config4_pretrain': cfg4, 'config5_action': cfg5,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -151,6 +151,13 @@ int mbx_tanh_bwd(const float* drep, const float* rep, void* dpre_t, size_t n, in
 size_t mbx_pose_loss_ws(int B, int T);
 int mbx_pose_loss(const float* pred, const float* gt, float lambda_scale, float lambda_velocity, float* losses, float* dpred,
                   float grad_scale, int B, int T, int J, void* ws, void* stream);
+/* 2D re-projection loss of the pre-training's 2D branch (lib/model/loss.py:72-77 loss_2d_weighted, train.py:200-203):
+ * loss[1] = mean |(pred_xy - target_xy) * conf| and, if dpred != NULL, dpred [B,T,J,3] = grad_scale * d loss / d pred (z row 0).
+ * pred [B,T,J,3] f32; target: x, y at target[tok * target_stride + {0,1}]; conf at conf[tok * conf_stride] -- with strides 3 / 3
+ * the [B,T,J,3] 2D batch itself is target and (channel 2) confidence.  ws: >= mbx_loss_2d_weighted_ws(B,T) bytes. */
+size_t mbx_loss_2d_weighted_ws(int B, int T);
+int mbx_loss_2d_weighted(const float* pred, const float* target, int target_stride, const float* conf, int conf_stride, float* loss,
+                         float* dpred, float grad_scale, int B, int T, int J, void* ws, void* stream);
 /* AdamW (torch.optim.AdamW semantics, train.py:289) over ONE flat fp32 buffer -- or one contiguous RANGE of it -- of n
  * parameters, one launch.  p, g, m, v are parallel buffers: 4-byte aligned, same offset within a 16-byte line (a range that
  * skips frozen parameters, learning.py:69-77 / train.py:284-289, need not start on a 16-byte boundary).

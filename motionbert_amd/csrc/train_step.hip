@@ -95,6 +95,48 @@ extern "C" int mbx_pose_loss(const float* pred, const float* gt, float lambda_sc
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 2D re-projection loss of the pre-training's 2D branch (lib/model/loss.py:72-77, used at train.py:200-203):
+//   loss = mean_{b,t,j} | (pred_xy - target_xy) * conf |          conf = detector confidence of the joint (train.py:164)
+//   d loss / d pred_xy = conf^2 (pred_xy - target_xy) / | (pred_xy - target_xy) conf | / n,   d / d pred_z = 0
+// (|.| = 0 contributes a zero gradient, as torch.norm's backward does).  pred [B,T,J,3]; target and conf are read with an
+// element stride so that the [B,T,J,3] 2D batch itself serves as both (x, y in channels 0-1, confidence in channel 2:
+// no deep copy of the confidence, train.py:164).  One wave per frame, lane j < J owns joint j; per-frame partial sums.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_2d_kernel(const float* __restrict__ pred, const float* __restrict__ target, int tstride,
+                                                      const float* __restrict__ conf, int cstride, float* __restrict__ part,
+                                                      float* __restrict__ dpred, float gscale, int nframes, int J) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x * 4 + wave;
+    if (frame >= nframes) return;                    // whole waves only
+    const bool on = lane < J;
+    const size_t tok = (size_t)frame * J + (on ? lane : 0);
+    const float inv_n = 1.0f / ((float)nframes * J);
+    float nrm = 0.f, g0 = 0.f, g1 = 0.f;
+    if (on) {
+        const float c = conf[tok * cstride];
+        const float r0 = (pred[tok * 3] - target[tok * tstride]) * c, r1 = (pred[tok * 3 + 1] - target[tok * tstride + 1]) * c;
+        nrm = sqrtf(fmaf(r0, r0, r1 * r1));
+        const float inv = nrm > 0.f ? c * inv_n / nrm : 0.f;
+        g0 = r0 * inv; g1 = r1 * inv;
+    }
+    if (on && dpred) { dpred[tok * 3] = gscale * g0; dpred[tok * 3 + 1] = gscale * g1; dpred[tok * 3 + 2] = 0.f; }
+    const float s = wave_sum(nrm) * inv_n;
+    if (lane == 0) part[frame] = s;
+}
+extern "C" size_t mbx_loss_2d_weighted_ws(int B, int T) { return (size_t)B * T * sizeof(float) + 256; }
+extern "C" int mbx_loss_2d_weighted(const float* pred, const float* target, int target_stride, const float* conf, int conf_stride,
+                                    float* loss, float* dpred, float grad_scale, int B, int T, int J, void* ws, void* stream) {
+    MBX_CHECK_ARG(pred && target && conf && loss && ws, "loss_2d_weighted: null pointer");
+    MBX_CHECK_ARG(B > 0 && T > 0 && J > 0 && J <= 64, "loss_2d_weighted: bad shape B=%d T=%d J=%d (J <= 64)", B, T, J);
+    MBX_CHECK_ARG(target_stride >= 2 && conf_stride >= 1, "loss_2d_weighted: target stride %d (>= 2), conf stride %d (>= 1)", target_stride, conf_stride);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_2d_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, pred, target, target_stride, conf, conf_stride,
+                       (float*)ws, dpred, grad_scale, B * T, J);
+    MBX_LAUNCH_CHECK("loss_2d_weighted");
+    return mbx_launch_colsum((const float*)ws, B * T, 1, 0, 1, loss, s);   // fixed order, no atomics: deterministic
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // AdamW over a flat buffer (torch.optim.AdamW, amsgrad=False, maximize=False):
 //   p *= 1 - lr wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
 // `state` = {step count t (float), learning rate} on the device: the tick kernel advances t, so a captured hipGraph replays

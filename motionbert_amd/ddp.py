@@ -89,6 +89,18 @@ class DistributedDSTformer(nn.Module):
                     dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                                    group=process_group)
 
+    def attach(self):
+        """Make every gradient-enabled forward of the WRAPPED module itself data-parallel (`module(x)`,
+        `module.get_representation(x)`, `module.get_pooled_representation(...)`): models that own the backbone as a sub-module
+        and call it directly -- `ActionNet.backbone` (model_action.py:62-70), a mesh regressor -- then need no change.  Returns
+        self.  `detach()` undoes it."""
+        self.module._grad_sync = _BucketSync(self.group, self._pending)
+        return self
+
+    def detach(self):
+        if hasattr(self.module, '_grad_sync'):
+            del self.module._grad_sync
+
     def wait(self):
         """Block (stream-level on GPU backends) until every outstanding gradient collective has finished.  Called by the
         backbone's backward; call it yourself before optimizer.step() only if the backbone took no part in backward."""

@@ -55,6 +55,8 @@ SIGNATURES = {
     'mbx_tanh_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     'mbx_pose_loss_ws': (_sz, [_i, _i]),
     'mbx_pose_loss': (_i, [_vp, _vp, _f, _f, _vp, _vp, _f, _i, _i, _i, _vp, _vp]),
+    'mbx_loss_2d_weighted_ws': (_sz, [_i, _i]),
+    'mbx_loss_2d_weighted': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp]),
     'mbx_pool_rep_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, C.c_uint64, _vp]),
     'mbx_tanh_pool_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, C.c_uint64, _i, _vp]),
     'mbx_dropout': (_i, [_vp, _vp, _sz, _f, C.c_uint64, _i, _vp]),
@@ -322,6 +324,22 @@ class HipOps:
         ws = self._ws(('pl', B, T), self.lib.mbx_pose_loss_ws, B, T, device=pred.device)
         self._ck(self.lib.mbx_pose_loss(_p(pred), _p(gt), float(lambda_scale), float(lambda_velocity), _p(losses), _p(dpred),
                                         float(grad_scale), B, T, J, _p(ws), self._stream()))
+
+    def loss_2d_weighted(self, pred, target, conf, loss, dpred, grad_scale=1.0):
+        """pred [B,T,J,3]; target [B,T,J,>=2] (x, y first) and conf [B,T,J] or [B,T,J,1] may be strided VIEWS of one [B,T,J,3]
+        2D batch (target = batch, conf = batch[..., 2]): only their last-dimension element stride is passed down."""
+        B, T, J, D = pred.shape
+        if D != 3 or tuple(target.shape[:3]) != (B, T, J) or target.shape[-1] < 2 or conf.numel() != B * T * J:
+            raise RuntimeError(f'libmbx: loss_2d_weighted needs pred [B,T,J,3], target [B,T,J,>=2], conf [B,T,J(,1)], got '
+                               f'{tuple(pred.shape)} / {tuple(target.shape)} / {tuple(conf.shape)}')
+        cf = conf.reshape(B, T, J) if conf.dim() == 4 else conf
+        ts, cs = target.stride(2), cf.stride(2)
+        if (target.stride(3) != 1 or target.stride(1) != J * ts or target.stride(0) != T * J * ts or
+                cf.stride(1) != J * cs or cf.stride(0) != T * J * cs or target.dtype != torch.float32 or cf.dtype != torch.float32):
+            raise RuntimeError('libmbx: loss_2d_weighted: target / conf must be fp32 and dense over (B, T, J) with a constant per-joint stride')
+        ws = self._ws(('l2d', B, T), self.lib.mbx_loss_2d_weighted_ws, B, T, device=pred.device)
+        self._ck(self.lib.mbx_loss_2d_weighted(_p(pred), _p(target), int(ts), _p(cf), int(cs), _p(loss), _p(dpred), float(grad_scale),
+                                               B, T, J, _p(ws), self._stream()))
 
     def adamw_step(self, p, g, m, v, state, beta1, beta2, eps, weight_decay, tick=True):
         self._ck(self.lib.mbx_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(state), float(beta1), float(beta2), float(eps),

@@ -54,6 +54,137 @@ def pose_loss(pred: torch.Tensor, gt: torch.Tensor, lambda_scale: float = 0.5, l
     return _PoseLossFn.apply(ops, pred, gt, float(lambda_scale), float(lambda_velocity))
 
 
+class _Loss2DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, pred, target, conf):
+        pred_c = pred.contiguous().float()
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred_c) if ctx.needs_input_grad[1] else None
+        ops.loss_2d_weighted(pred_c, target, conf, loss, dpred)
+        ctx.dpred = dpred
+        return loss[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dloss):
+        d = ctx.dpred
+        ctx.dpred = None
+        return None, (d * dloss if d is not None else None), None, None
+
+
+def loss_2d_weighted(pred: torch.Tensor, target: torch.Tensor, conf: torch.Tensor, ops=None) -> torch.Tensor:
+    """`mean(|| (pred[..., :2] - target[..., :2]) * conf ||)` (lib/model/loss.py:72-77; the 2D branch of pre-training,
+    train.py:200-203) with its gradient in the same kernel pass.  `target` [B,T,J,>=2] and `conf` [B,T,J,1] may be views of
+    the 2D batch itself (`batch_gt`, `batch_input[..., 2:]`): no deep copy of the confidence (train.py:164)."""
+    if ops is None:
+        from . import hip_ops
+        ops = hip_ops.get()
+    return _Loss2DFn.apply(ops, pred, target.detach(), conf.detach())
+
+
+class PretrainStep:
+    """One optimizer step of the reference's `train_epoch` (train.py:155-206) with every piece on the device:
+
+        step = PretrainStep(net, optimizer, aug=Augmenter2D(args), rootrel=True, mask=True, noise=True,
+                            lambda_scale=0.5, lambda_velocity=20.0)               # configs/pretrain/MB_pretrain.yaml
+        losses = step(batch_input, batch_gt, has_3d=True, has_gt=True)          # 3D batches  [B,243,17,3]
+        losses = step(batch_2d, batch_2d, has_3d=False, has_gt=...)            # 2D batches  [B,81|30,17,3], target = input
+
+    has_3d: pose losses `loss_mpjpe + lambda_scale * n_mpjpe + lambda_3d_velocity * loss_velocity` (the other lambdas are 0
+    in every shipped config and are refused otherwise) -> `losses` = [mpjpe, n_mpjpe, velocity, total];
+    not has_3d: `loss_2d_weighted(pred, batch_gt, conf)` with conf = the input's third channel BEFORE augmentation
+    (train.py:163-164) -> `losses` = [0, 0, 0, 2d_proj].  `rootrel`: batch_gt -= batch_gt[:, :, 0:1] (train.py:165-166), else the
+    depth of the first frame's root is moved to 0 (:168).  `aug.augment2D(batch_input, noise=noise and has_gt, mask=mask)`
+    (train.py:169-170) runs as one kernel (motionbert_amd.augment).  No `.item()`: the loss values stay on the device.
+    `net` is the backbone or its `DistributedDSTformer` wrapper; under data parallelism every rank must call the step the
+    same number of times per loader (`pretrain_epoch_plan`), the gradient all-reduce is the only exchange."""
+
+    def __init__(self, net, optimizer, aug=None, rootrel: bool = True, mask: bool = True, noise: bool = True, no_conf: bool = False,
+                 lambda_scale: float = 0.5, lambda_velocity: float = 20.0, lambda_lv=0.0, lambda_lg=0.0, lambda_a=0.0, lambda_av=0.0):
+        if any(float(v) != 0.0 for v in (lambda_lv, lambda_lg, lambda_a, lambda_av)):
+            raise NotImplementedError('limb / angle losses (lambda_lv, lambda_lg, lambda_a, lambda_av) are 0 in every shipped config; '
+                                      'only loss_mpjpe + n_mpjpe + loss_velocity are fused')
+        if (mask or noise) and aug is None:
+            raise ValueError('mask / noise need an Augmenter2D (motionbert_amd.augment.Augmenter2D(args))')
+        self.net, self.opt, self.aug = net, optimizer, aug
+        self.rootrel, self.mask, self.noise, self.no_conf = rootrel, mask, noise, no_conf
+        self.ls, self.lv = float(lambda_scale), float(lambda_velocity)
+
+    def __call__(self, batch_input: torch.Tensor, batch_gt: torch.Tensor, has_3d: bool, has_gt: bool = True, seed=None) -> torch.Tensor:
+        with torch.no_grad():
+            conf = None
+            if self.no_conf:
+                batch_input = batch_input[..., :2]
+            if not has_3d:
+                conf = batch_input[..., 2:]                      # a view: the augmentation below returns a NEW tensor
+            if self.rootrel:
+                batch_gt = batch_gt - batch_gt[:, :, 0:1, :]
+            else:
+                batch_gt = batch_gt.clone()
+                batch_gt[..., 2] = batch_gt[..., 2] - batch_gt[:, 0:1, 0:1, 2]
+            if self.mask or self.noise:
+                batch_input = self.aug.augment2D(batch_input, noise=(self.noise and has_gt), mask=self.mask, seed=seed)
+        pred = self.net(batch_input)
+        self.opt.zero_grad(set_to_none=True)
+        if has_3d:
+            total, losses = pose_loss(pred, batch_gt, self.ls, self.lv)
+        else:
+            total = loss_2d_weighted(pred, batch_gt, conf)
+            z = total.detach() * 0
+            losses = torch.stack([z, z, z, total.detach()])
+        total.backward()
+        self.opt.step()
+        return losses
+
+
+def pretrain_epoch_plan(n_posetrack: int, n_instav: int, n_3d: int, epoch: int, train_2d: bool = True, curriculum: int = 30):
+    """The loader sequence of one pre-training epoch (train.py:325-330): from epoch `pretrain_3d_curriculum` on, every
+    PoseTrack batch, then every InstaVariety batch, then the 3D batches -- [(loader, has_3d, has_gt, n_batches)].  The batch
+    counts must be the per-rank counts of equal shards (PackedMotion3D.epoch_indices wraps the tail like DistributedSampler):
+    all ranks then issue the same steps in the same order and the gradient all-reduces pair up."""
+    plan = []
+    if train_2d and epoch >= curriculum:
+        plan += [('posetrack', False, True, int(n_posetrack)), ('instav', False, False, int(n_instav))]
+    plan.append(('3d', True, True, int(n_3d)))
+    return plan
+
+
+class ActionStep:
+    """One optimizer step of train_action.py:172-188: scores = ActionNet(batch [N,M,T,17,3]), cross-entropy, backward, and the
+    two AdamW groups of train_action.py:143-149 -- backbone at `lr_backbone`, head at `lr_head`
+    (MB_ft_NTU60_xsub.yaml:7-9) -- as two flat one-launch optimizers; `decay()` is the per-epoch StepLR(gamma=lr_decay).
+    `distributed=True` (after init_process_group): the backbone is wrapped as `DistributedDSTformer(backbone, extra=model.head)`
+    and attached, so that `model(batch)` itself all-reduces the backbone's gradient buckets while backward runs and the head's
+    gradients by post-accumulate hooks (they come first in backward); BatchNorm statistics stay per rank as under the
+    reference's nn.DataParallel."""
+
+    def __init__(self, model, lr_backbone: float = 1e-4, lr_head: float = 1e-3, weight_decay: float = 0.01, distributed: bool = False,
+                 process_group=None, ops=None):
+        self.model, self.ddp = model, None
+        if distributed:
+            from .ddp import DistributedDSTformer
+            self.ddp = DistributedDSTformer(model.backbone, process_group=process_group, extra=model.head, ops=ops).attach()
+        self.opt_backbone = FlatAdamW(model.backbone, lr=lr_backbone, weight_decay=weight_decay)
+        self.opt_head = FlatAdamW([('head.' + n, p) for n, p in model.head.named_parameters() if p.requires_grad], lr=lr_head,
+                                  weight_decay=weight_decay)
+
+    def __call__(self, batch_input: torch.Tensor, labels: torch.Tensor):
+        out = self.model(batch_input)
+        self.opt_backbone.zero_grad(set_to_none=True)
+        self.opt_head.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(out, labels)
+        loss.backward()
+        if self.ddp is not None:
+            self.ddp.wait()                      # (the backbone's backward already waited; covers a frozen backbone)
+        self.opt_backbone.step()
+        self.opt_head.step()
+        return loss.detach(), out.detach()
+
+    def decay(self, gamma: float):
+        self.opt_backbone.lr = self.opt_backbone.lr * gamma
+        self.opt_head.lr = self.opt_head.lr * gamma
+
+
 def flat_layout(names, shapes, depth):
     """Offsets of every parameter in the flat buffer, in backward-completion order (tail | levels last..first | embedding):
     the layout `_DSTformerFn.backward` uses for the gradients."""

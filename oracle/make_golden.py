@@ -275,6 +275,33 @@ def pose_loss_fixture():
     np.savez_compressed(os.path.join(ROOT, 'tests/golden', 'pose_loss.npz'), **save)
 
 
+def loss_2d_fixture():
+    """VERDICT r2 item 7 / SURVEY 8d config 4: the reference's own loss_2d_weighted (loss.py:72-77) as the 2D branch of
+    train_epoch uses it (train.py:163-166,200-203): the target IS the 2D batch (x, y, confidence), made root-relative, the
+    confidence is the input's third channel; fp64 loss and autograd gradient with respect to the 3D prediction.  Case 'z'
+    contains joints with zero confidence and joints where prediction == target (|.| = 0 -> zero gradient)."""
+    L = import_reference_loss()
+    save = {}
+    for tag, (B, T) in (('a', (3, 30)), ('b', (2, 81)), ('z', (2, 5))):
+        g = torch.Generator().manual_seed(300 + T)
+        xy = torch.rand(B, T, 17, 2, generator=g) * 2 - 1
+        conf = torch.rand(B, T, 17, 1, generator=g)
+        if tag == 'z':
+            conf[0, :, 3] = 0.0
+        batch = torch.cat([xy, conf], -1).double()                      # motion_2d, returned as (input, target) by the 2D datasets
+        target = batch - batch[:, :, 0:1, :]                            # rootrel (train.py:165-166)
+        pred = (torch.randn(B, T, 17, 3, generator=g) * 0.4).double()
+        if tag == 'z':
+            pred[1, 2, 5, :2] = target[1, 2, 5, :2]
+        pred.requires_grad_(True)
+        loss = L.loss_2d_weighted(pred, target, batch[..., 2:])
+        loss.backward()
+        save.update({f'{tag}.batch': batch.numpy().astype(np.float32), f'{tag}.pred': pred.detach().numpy().astype(np.float32),
+                     f'{tag}.loss': np.asarray(loss.item()), f'{tag}.dpred': pred.grad.numpy()})
+        print(f'[loss_2d {tag}] {loss.item():.6f}')
+    np.savez_compressed(os.path.join(ROOT, 'tests/golden', 'loss_2d.npz'), **save)
+
+
 def actionnet_fixture(DST):
     """the reference's own ActionNet (lib/model/model_action.py) on a small reference backbone, evaluation
     mode (BatchNorm on perturbed running statistics) and training mode (batch statistics, dropout 0): class scores, the
@@ -468,7 +495,7 @@ def main():
     only = sys.argv[1:]
     if only:      # e.g. `python oracle/make_golden.py lite_2x81 full_1x243` regenerates just those
         for name in only:
-            {'pose_loss': pose_loss_fixture, 'actionnet': lambda: actionnet_fixture(DST), 'dropout': lambda: dropout_fixture(DST), 'augment': augment_fixture,
+            {'pose_loss': pose_loss_fixture, 'loss_2d': loss_2d_fixture, 'actionnet': lambda: actionnet_fixture(DST), 'dropout': lambda: dropout_fixture(DST), 'augment': augment_fixture,
              'lite_2x81': lambda: baseline_shape(DST, 'lite_2x81', LITE_KW, 2, 81, None),
              'full_1x243': lambda: baseline_shape(DST, 'full_1x243', FULL_KW, 1, 243, 5)}[name]()
         return
@@ -479,6 +506,7 @@ def main():
     baseline_shape(DST, 'lite_2x81', LITE_KW, 2, 81, None)
     baseline_shape(DST, 'full_1x243', FULL_KW, 1, 243, 5)
     pose_loss_fixture()
+    loss_2d_fixture()
     actionnet_fixture(DST)
     dropout_fixture(DST)
     augment_fixture()

@@ -104,7 +104,16 @@ def _head_worker(rank, world, port, q):
         x = make_input(4, 9, 17, 31)
         labels = torch.tensor([1, 4, 0, 2])
         lo, hi = rank * 2, rank * 2 + 2
-        rep = ddp.get_representation(x[lo:hi])                                  # [2, 9, 17, R]  (model_action.py:68)
+        if rank == 0:
+            rep = ddp.get_representation(x[lo:hi])                              # [2, 9, 17, R]  (model_action.py:68)
+        else:
+            # attach(): a model that owns the backbone and calls IT (ActionNet.backbone) -- the sync rides on the module
+            from motionbert_amd import model as Mm
+            ddp.attach()
+            assert backbone._grad_sync.pending is ddp._pending
+            rep = Mm.run(MockOps(), backbone, x[lo:hi], True, backbone._grad_sync)
+            ddp.detach()
+            assert not hasattr(backbone, '_grad_sync')
         logits = head(rep.mean(1).reshape(2, -1))                                # mean over T, joints flattened (:20-24)
         loss = torch.nn.functional.cross_entropy(logits, labels[lo:hi])
         loss.backward()

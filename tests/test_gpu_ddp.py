@@ -100,3 +100,78 @@ def test_two_ranks_real_kernels_match_single_process():
     den = np.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in model.parameters()))
     print(f'two ranks vs one process, all gradients: rel-L2 {num / den:.3e}')
     assert num / den < 1e-2, num / den
+
+
+def _action_worker(rank, world, port, backend, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    ndev = torch.cuda.device_count()
+    dev = torch.device('cuda', rank % ndev)
+    torch.cuda.set_device(dev)
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        from motionbert_amd.action import ActionNet
+        from motionbert_amd.train import ActionStep
+        torch.manual_seed(300 + rank)                          # different init per rank: the broadcast must fix backbone AND head
+        cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128)
+        net = ActionNet(backbone=build_model(cfg), dim_rep=128, num_classes=60, dropout_ratio=0., version='class', num_joints=17).to(dev)
+        net.backbone.precision = 'fp32'
+        net.train()
+        net.head.bn.eval()                                      # running statistics: per-rank half batches then add up exactly
+        step = ActionStep(net, lr_backbone=1e-4, lr_head=1e-3, weight_decay=0.01, distributed=True)
+        x = torch.stack([make_input(2, 27, 17, 80 + i) for i in range(4)]).to(dev)       # [N=4, M=2, T, 17, 3]
+        labels = torch.tensor([3, 7, 59, 0], device=dev)
+        lo, hi = rank * 2, rank * 2 + 2
+        for _ in range(2):
+            loss, _o = step(x[lo:hi], labels[lo:hi])
+        torch.cuda.synchronize()
+        q.put((rank, backend, {n: p.detach().cpu().numpy() for n, p in net.named_parameters()}, float(loss)))
+    except Exception as e:
+        import traceback
+        q.put((rank, 'error', f'{type(e).__name__}: {e}\n{traceback.format_exc()}', None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_action_step_matches_single_process():
+    """BASELINE config 5 under data parallelism: ActionStep(distributed=True) -- backbone buckets and the
+    ActionNet head's gradients mean-all-reduced, two flat AdamW groups -- on two ranks with half the batch each must end
+    where one process with the whole batch ends."""
+    from motionbert_amd.action import ActionNet
+    from motionbert_amd.train import ActionStep
+    backend = 'nccl' if torch.cuda.device_count() >= 2 else 'gloo'
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_action_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, be, w, loss = q.get(timeout=420)
+        res[r] = (be, w, loss)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(v[0] == backend for v in res.values()), {r: v[:2] for r, v in res.items() if v[0] == 'error'}
+    torch.manual_seed(300)
+    cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128)
+    net = ActionNet(backbone=build_model(cfg), dim_rep=128, num_classes=60, dropout_ratio=0., version='class', num_joints=17).to('cuda')
+    net.backbone.precision = 'fp32'
+    net.train()
+    net.head.bn.eval()
+    step = ActionStep(net, lr_backbone=1e-4, lr_head=1e-3, weight_decay=0.01)
+    x = torch.stack([make_input(2, 27, 17, 80 + i) for i in range(4)]).to('cuda')
+    labels = torch.tensor([3, 7, 59, 0], device='cuda')
+    for _ in range(2):
+        step(x, labels)
+    for n, p in net.named_parameters():
+        assert np.array_equal(res[0][1][n], res[1][1][n]), f'ranks ended with different {n}'
+        lr = 1e-3 if n.startswith('head.') else 1e-4
+        ref = p.detach().cpu().numpy()
+        assert float(np.abs(res[0][1][n] - ref).max()) <= 2 * lr * 2, n         # Adam turns rounding noise on ~0 gradients into +-lr steps
+        if p.ndim >= 2 and 'ts_attn' not in n:
+            assert float(np.linalg.norm(res[0][1][n] - ref) / np.linalg.norm(ref)) < 1e-4, n

@@ -226,3 +226,122 @@ def test_graphed_train_step_matches_eager_steps():
             ob.lr = 1e-4
     assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters())), 'graph replay and eager steps must be bit-identical'
     assert float(oa.state_t[0]) == 3.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5: the pre-training step with its 2D branch, the ActionNet step
+# ------------------------------------------------------------------------------------------------------------------
+def _ref_loss_2d(pred, target, conf):
+    """lib/model/loss.py:72-77 restated; pinned against the REAL reference by tests/golden/loss_2d.npz."""
+    return torch.mean(torch.norm((pred[..., :2] - target[..., :2]) * conf, dim=-1))
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'z'])
+def test_loss_2d_weighted_matches_reference_fixture(tag):
+    from motionbert_amd.train import loss_2d_weighted
+    z = np.load('tests/golden/loss_2d.npz')
+    batch = torch.from_numpy(z[f'{tag}.batch']).to(DEV)
+    pred = torch.from_numpy(z[f'{tag}.pred']).to(DEV).requires_grad_(True)
+    target = batch - batch[:, :, 0:1, :]                      # rootrel, train.py:165-166
+    loss = loss_2d_weighted(pred, target, batch[..., 2:])     # confidence = a strided view of the batch (no copy)
+    (loss * 1.5).backward()
+    assert abs(float(loss) - float(z[f'{tag}.loss'])) <= 2e-5 * float(z[f'{tag}.loss'])
+    assert rel_l2(pred.grad.cpu().numpy(), 1.5 * z[f'{tag}.dpred']) < 2e-5
+    assert float(pred.grad[..., 2].abs().max()) == 0.0
+    p64 = torch.from_numpy(z[f'{tag}.pred']).double()
+    b64 = torch.from_numpy(z[f'{tag}.batch']).double()
+    assert abs(float(_ref_loss_2d(p64, b64 - b64[:, :, 0:1], b64[..., 2:])) - float(z[f'{tag}.loss'])) < 1e-6
+    with pytest.raises(RuntimeError):
+        loss_2d_weighted(pred, target[:, :, :5], batch[..., 2:])
+
+
+def _aug_from_fixture():
+    from motionbert_amd.augment import Augmenter2D
+    z = np.load('tests/golden/augment2d.npz')
+    d = z['d2c']
+    return Augmenter2D(noise=dict(mean=torch.from_numpy(z['noise_mean']), std=torch.from_numpy(z['noise_std']), weight=torch.from_numpy(z['noise_weight'])),
+                       d2c=dict(a=float(d[0]), b=float(d[1]), m=float(d[2]), s=float(d[3])), mask_ratio=0.05, mask_T_ratio=0.1)
+
+
+def test_pretrain_step_matches_the_restated_reference_loop():
+    """train.py:155-206 (MB_pretrain.yaml: rootrel, mask + noise, lambda_scale 0.5, lambda_3d_velocity 20): one PoseTrack-like 2D
+    batch (T=30, has_gt), one InstaVariety-like 2D batch (T=81, no noise), one 3D batch, through PretrainStep on model `a`
+    and through the reference's statements restated with torch ops (same augmented input via the same seed, the reference's
+    loss formulas, FlatAdamW) on model `b`: same losses, same parameters afterwards."""
+    from motionbert_amd.train import FlatAdamW, PretrainStep
+    a = build_model(LITE, seed=6).to(DEV)
+    b = build_model(LITE, seed=6).to(DEV)
+    for m in (a, b):
+        m.precision = 'fp32'
+    oa, ob = FlatAdamW(a, lr=5e-4, weight_decay=0.01), FlatAdamW(b, lr=5e-4, weight_decay=0.01)
+    aug = _aug_from_fixture()
+    step = PretrainStep(a, oa, aug=aug, rootrel=True, mask=True, noise=True, lambda_scale=0.5, lambda_velocity=20.0)
+    g = torch.Generator().manual_seed(9)
+    batches = [(make_input(3, 30, 17, 71).to(DEV), None, False, True), (make_input(2, 81, 17, 72).to(DEV), None, False, False),
+               (make_input(2, 27, 17, 73).to(DEV), (torch.randn(2, 27, 17, 3, generator=g) * 0.3).to(DEV), True, True)]
+    for k, (x, gt, has_3d, has_gt) in enumerate(batches):
+        gt = x if gt is None else gt                          # the 2D datasets return (motion_2d, motion_2d)
+        x0 = x.clone()
+        la = step(x, gt, has_3d=has_3d, has_gt=has_gt, seed=1000 + k)
+        assert torch.equal(x, x0), 'the step must not modify the batch it was handed'
+        # ---- the reference's statements
+        conf = x[..., 2:].clone()
+        tgt = gt - gt[:, :, 0:1, :]
+        xin = aug.augment2D(x, noise=has_gt, mask=True, seed=1000 + k)
+        pred = b(xin)
+        ob.zero_grad(set_to_none=True)
+        if has_3d:
+            r = _ref_losses(pred, tgt, 0.5, 20.0)
+            total, lb = r[3], torch.stack([v.detach() for v in r])
+        else:
+            total = _ref_loss_2d(pred, tgt, conf)
+            lb = torch.stack([total.detach() * 0] * 3 + [total.detach()])
+        total.backward()
+        ob.step()
+        assert torch.allclose(la, lb.float(), rtol=2e-5, atol=1e-7), (k, la, lb)
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert float((p - q).abs().max()) <= 2 * 5e-4 * 3, n
+        if p.ndim >= 2 and not n.startswith('ts_attn'):
+            assert float((p - q).norm() / q.norm()) < 1e-4, (n, float((p - q).norm() / q.norm()))
+    with pytest.raises(NotImplementedError):
+        PretrainStep(a, oa, aug=aug, lambda_lv=0.1)
+
+
+def test_action_step_two_lr_groups_match_torch_adamw():
+    """train_action.py:143-149,172-188: AdamW with the backbone at lr_backbone and the head at lr_head (MB_ft_NTU60_xsub.yaml:
+    7-9), cross-entropy on ActionNet scores -- ActionStep (two flat optimizers, fused pooling tail, unused backbone head
+    untouched) against torch.optim.AdamW with the same two parameter groups on an identical copy."""
+    from motionbert_amd.action import ActionNet
+    from motionbert_amd.train import ActionStep
+    cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128)
+
+    def mk():
+        torch.manual_seed(91)
+        net = ActionNet(backbone=build_model(cfg), dim_rep=128, num_classes=60, dropout_ratio=0., version='class', hidden_dim=2048, num_joints=17).to(DEV)
+        net.backbone.precision = 'fp32'
+        return net.train()
+    a, b = mk(), mk()
+    step = ActionStep(a, lr_backbone=1e-4, lr_head=1e-3, weight_decay=0.01)
+    ob = torch.optim.AdamW([{'params': [p for p in b.backbone.parameters() if p.requires_grad], 'lr': 1e-4},
+                            {'params': list(b.head.parameters()), 'lr': 1e-3}], lr=1e-4, weight_decay=0.01)
+    x = torch.stack([make_input(2, 27, 17, 80 + i) for i in range(4)]).to(DEV)           # [N=4, M=2, T, 17, 3]
+    labels = torch.tensor([3, 7, 59, 0], device=DEV)
+    hw = a.backbone.head.weight.detach().clone()
+    for it in range(3):
+        la, _ = step(x, labels)
+        ob.zero_grad(set_to_none=True)
+        lb = torch.nn.functional.cross_entropy(b(x), labels)
+        lb.backward()
+        ob.step()
+        assert abs(float(la) - float(lb)) < 1e-4 * abs(float(lb)), (it, float(la), float(lb))
+        if it == 1:
+            step.decay(0.99)
+            for gk in ob.param_groups:
+                gk['lr'] *= 0.99
+    assert torch.equal(a.backbone.head.weight, hw), 'the backbone head is unused on the representation path: no decay, no update'
+    assert torch.equal(b.backbone.head.weight, hw)
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        lr = 1e-3 if n.startswith('head.') else 1e-4
+        assert float((p - q).abs().max()) <= 2 * lr * 3, n
+        if p.ndim >= 2 and 'ts_attn' not in n:
+            assert float((p - q).norm() / q.norm()) < 1e-4, (n, float((p - q).norm() / q.norm()))

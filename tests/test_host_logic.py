@@ -235,3 +235,12 @@ def test_recompute_mode_rebuilds_what_it_does_not_save(precision):
     assert calls[1].count('layernorm_fwd') == calls[0].count('layernorm_fwd') + 8 * depth and calls[1].count('gelu_fwd') == 4 * depth
     worst = max(float((grads[0][n] - grads[1][n]).norm() / grads[0][n].norm().clamp_min(1e-20)) for n in grads[0])
     assert worst == 0.0 if precision != 'bf16' else worst < 2e-2, worst
+
+
+def test_pretrain_epoch_plan_follows_the_reference_curriculum():
+    """train.py:325-330: before `pretrain_3d_curriculum` only 3D batches; afterwards PoseTrack (has_gt), InstaVariety (no gt),
+    then 3D -- the same list on every rank, so data-parallel ranks step the loaders in lock-step."""
+    from motionbert_amd.train import pretrain_epoch_plan
+    assert pretrain_epoch_plan(5, 7, 11, epoch=0) == [('3d', True, True, 11)]
+    assert pretrain_epoch_plan(5, 7, 11, epoch=30) == [('posetrack', False, True, 5), ('instav', False, False, 7), ('3d', True, True, 11)]
+    assert pretrain_epoch_plan(5, 7, 11, epoch=40, train_2d=False) == [('3d', True, True, 11)]
