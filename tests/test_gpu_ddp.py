@@ -115,7 +115,7 @@ def _action_worker(rank, world, port, backend, q):
         from motionbert_amd.action import ActionNet
         from motionbert_amd.train import ActionStep
         torch.manual_seed(300 + rank)                          # different init per rank: the broadcast must fix backbone AND head
-        cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128)
+        cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128, num_heads=4)      # head dim 32 (the kernels take 32 or 64)
         net = ActionNet(backbone=build_model(cfg), dim_rep=128, num_classes=60, dropout_ratio=0., version='class', num_joints=17).to(dev)
         net.backbone.precision = 'fp32'
         net.train()
@@ -158,7 +158,7 @@ def test_two_ranks_action_step_matches_single_process():
         p.join(timeout=60)
     assert all(v[0] == backend for v in res.values()), {r: v[:2] for r, v in res.items() if v[0] == 'error'}
     torch.manual_seed(300)
-    cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128)
+    cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128, num_heads=4)      # head dim 32 (the kernels take 32 or 64)
     net = ActionNet(backbone=build_model(cfg), dim_rep=128, num_classes=60, dropout_ratio=0., version='class', num_joints=17).to('cuda')
     net.backbone.precision = 'fp32'
     net.train()

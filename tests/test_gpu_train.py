@@ -313,7 +313,7 @@ def test_action_step_two_lr_groups_match_torch_adamw():
     untouched) against torch.optim.AdamW with the same two parameter groups on an identical copy."""
     from motionbert_amd.action import ActionNet
     from motionbert_amd.train import ActionStep
-    cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128)
+    cfg = dict(LITE, depth=2, dim_feat=128, dim_rep=128, num_heads=4)      # head dim 32 (the kernels take 32 or 64)
 
     def mk():
         torch.manual_seed(91)
