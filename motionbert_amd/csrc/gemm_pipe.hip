@@ -847,6 +847,33 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int tok0, int col0
     return f.v;
 }
 
+// The same fragment through INLINE ASM.  Why: the compiler cannot see that the explicit `s_waitcnt vmcnt(N)` + s_barrier
+// pairs of the ring protocol order the LDS-DMA writes before the fragment reads, and for the transpose-read builtin (unlike
+// a plain LDS load) its waitcnt pass puts `s_waitcnt vmcnt(0)` in front of the first read of every chunk -- i.e. it drains
+// the whole LDS-DMA ring once per chunk (found in round 3 by reading the ISA of the shipped gemm_tn_pipe256 loop: the
+// "three chunks in flight" were one).  An asm read is invisible to that pass; in exchange the kernel owns the lgkmcnt
+// bookkeeping: results may only be used behind an explicit s_waitcnt, and TR_TIE makes that a data dependence.
+#ifndef MBX_TR_ASM
+#define MBX_TR_ASM 1
+#endif
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t tr_frag_a(const char* tile, int tok0, int col0, int lane) {
+#if MBX_TR_ASM
+    const int g = lane >> 5, r16 = lane & 15, nb = col0 + 16 * ((lane >> 4) & 1) + 4 * (r16 & 3);
+    const int t = tok0 + 8 * g + (r16 >> 2);
+    const uint32_t a = (uint32_t)(uintptr_t)(lds_void_t*)(tile + tr_off<ROWB>(t, nb));   // rows t and t + 4 share the swizzle
+    union { v4s_t h[2]; bf16x8_t v; } f;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.h[0]) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.h[1]) : "v"(a), "n"(4 * ROWB) : "memory");
+    return f.v;
+#else
+    return tr_frag<ROWB>(tile, tok0, col0, lane);
+#endif
+}
+// `s_waitcnt <what>` as a data dependence of the six fragments of one register set (see tr_frag_a)
+#define TR_WAIT6(what_, f0, f1, f2, f3, f4, f5) \
+    asm volatile("s_waitcnt " what_ : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) : : "memory")
+
 __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A,
                                                               float* __restrict__ part_w, float* __restrict__ part_b, int M,
                                                               int N, int K, int ntk, int ntiles, int nsplits,
@@ -1076,9 +1103,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
         const char* sY_ = smem + (stage_) * U_STAGE;                                                                 \
         const char* sA_ = sY_ + U_TILE;                                                                              \
         _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                           \
-            _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) fy[s_][t_] = tr_frag<512>(sY_, 16 * s_, wr * 128 + t_ * 32, lane); \
-            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) fa[s_][t_] = tr_frag<512>(sA_, 16 * s_, wc * 64 + t_ * 32, lane);  \
+            _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) fy[s_][t_] = tr_frag_a<512>(sY_, 16 * s_, wr * 128 + t_ * 32, lane); \
+            _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) fa[s_][t_] = tr_frag_a<512>(sA_, 16 * s_, wc * 64 + t_ * 32, lane);  \
         }                                                                                                            \
+    } while (0)
+    // behind the explicit lgkmcnt(0): zero the tokens past M (X3: per pass)
+#define U_FIX(vc_)                                                                                                   \
+    do {                                                                                                             \
         const int p1_ = X3 && (vc_) >= nchunks1, p2_ = X3 && (vc_) >= 2 * nchunks1;                                  \
         const int valid_ = M - ((vc_) - (p1_ ? nchunks1 : 0) - (p2_ ? nchunks1 : 0)) * U_BMS;                        \
         if (valid_ < U_BMS) {   /* last chunk of a pass: rows were clamped to M-1 (duplicates) -> zero their contribution */ \
@@ -1105,6 +1136,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     for (int c = 0; c < nc; ++c) {
         const int vc = c_beg + c;
         U_READ(stage, vc);
+        // own share of chunk c+1 landed (c+2 may fly); the fragments have arrived (asm reads: nothing may touch them earlier)
+        if (nc - 1 - c >= 2) {
+            TR_WAIT6("vmcnt(4) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
+        } else {
+            TR_WAIT6("vmcnt(0) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
+        }
+        TR_WAIT6("lgkmcnt(0)", fy[1][0], fy[1][1], fy[1][2], fy[1][3], fa[1][0], fa[1][1]);
+        U_FIX(vc);
         // X3: pass 1 streams dY_hi a second time -> it must not count twice in the bias gradient
         if (want_db && !(X3 && vc >= nchunks1 && vc < 2 * nchunks1)) {
 #pragma unroll
@@ -1117,8 +1156,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
                     for (int e = 0; e < 4; ++e) bsum[t_] += __uint_as_float(z.u[e] << 16) + __uint_as_float(z.u[e] & 0xffff0000u);
                 }
         }
-        if (nc - 1 - c >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // own share of chunk c+1 landed; c+2 may fly
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         U_BARRIER();
         if (c + 3 < nc) U_ISSUE(vc + 3, (stage + 3) & 3);
         U_MMA();
@@ -1128,6 +1165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     if (!trailing) __builtin_amdgcn_s_barrier();
 #undef U_BARRIER
 #undef U_MMA
+#undef U_FIX
 #undef U_READ
 #undef U_ISSUE
     const int i = lane & 31, g = lane >> 5;
@@ -1185,8 +1223,8 @@ int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db,
     float* part_b = db ? (splits == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
     if (big) {
         const size_t shm256 = 4 * U_STAGE;
-        if (set_lds_attr(gemm_tn_pipe256_kernel<false>, shm256, "gemm_tn_pipe256")) return 1;
         const int ntiles256 = ntn * ntk, groups256 = (splits + 7) / 8;
+        if (set_lds_attr(gemm_tn_pipe256_kernel<false>, shm256, "gemm_tn_pipe256")) return 1;
         hipLaunchKernelGGL(gemm_tn_pipe256_kernel<false>, dim3(8 * groups256 * ntiles256), dim3(512), shm256, s, (const bf16_t*)dy,
                            (const bf16_t*)a, (const bf16_t*)nullptr, (const bf16_t*)nullptr, part_w, part_b, M, N, K, ntk, ntiles256,
                            splits, cps);
