@@ -76,6 +76,11 @@ def pose_loss(pred, gt):
     return mpjpe + LAMBDA_SCALE * nm + LAMBDA_VELOCITY * vel
 
 
+# the NT GEMM entries of the C ABI (same kernels, different epilogues): mbx_gemm_nt, and with LayerNorm folding the GELU' epilogue
+# that also emits row dots and the dX GEMM whose epilogue is the LayerNorm backward
+NT_FAMILY = ('gemm_nt', 'gemm_nt_dgelu_stats', 'gemm_nt_lnbwd')
+
+
 class TimedOps:
     """Wraps the kernel provider for ONE instrumented step: HIP events around every C-ABI call."""
 
@@ -86,7 +91,7 @@ class TimedOps:
 
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
-        if not callable(fn) or name.startswith('_'):
+        if not callable(fn) or name.startswith('_') or name.startswith('can_'):
             return fn
 
         def wrapped(*a, **k):
@@ -95,7 +100,7 @@ class TimedOps:
             r = fn(*a, **k)
             e1.record()
             flops = 0.0
-            if name == 'gemm_nt':
+            if name in NT_FAMILY:
                 flops = 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]
             elif name == 'gemm_tn':
                 flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
@@ -262,7 +267,7 @@ def bench_block(dev, B=256, T=243, iters=5):
     J, C = cfg.J, cfg.C
     M = B * T * J
     eng.dev, eng.B, eng.Tlen, eng.M = dev, B, T, M
-    eng.Wn, eng.Wt = ops.prep_weights(P, linear_names(cfg), torch.bfloat16, True)
+    eng.prepare_weights(True)
     g = torch.Generator(device=dev).manual_seed(3)
     h = torch.randn(M, C, device=dev, generator=g)
     dy = torch.randn(M, C, device=dev, generator=g) * 0.01
@@ -656,7 +661,10 @@ def main():
         tot = sum(d['ms'] for d in agg.values())
         breakdown = {k: dict(calls=d['calls'], ms=round(d['ms'], 3), share=round(d['ms'] / tot, 4)) for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
         dom = max(agg, key=lambda k: agg[k]['ms'])
-        d = agg['gemm_nt']
+        d = dict(calls=0, ms=0.0, flops=0.0)
+        for k in NT_FAMILY:
+            for f in d:
+                d[f] += agg.get(k, {}).get(f, 0)
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
         traffic = pmc_traffic_bytes(B, T, args.precision)
@@ -666,7 +674,7 @@ def main():
         intensity = fpl / traffic if traffic else None
         bound = 'hbm' if intensity is not None and intensity < peak / HBM_ACHIEVABLE_TBS else 'mfma'
         hbm_tbs = traffic / avg_s / 1e12 if traffic else None
-        roof = dict(bound=bound, kernel='mbx_gemm_nt -> gemm_nt_pp256_kernel (store, GELU, dGELU epilogues) / gemm_nt_pipe_kernel (residual epilogue) (bf16 MFMA GEMM, all 162 launches of a step)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+        roof = dict(bound=bound, kernel='mbx_gemm_nt / mbx_gemm_nt_dgelu_stats / mbx_gemm_nt_lnbwd -> gemm_nt_pp256_kernel (store, GELU, dGELU epilogues) / gemm_nt_pipe_kernel (residual and LayerNorm-backward epilogues) (bf16 MFMA GEMM, all 162 launches of a step)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                     traffic=traffic, traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt kernels)',
                     traffic_source=('STATIC: ' + os.path.relpath(PMC_TABLE, ROOT) + ' (separate rocprofv3 --pmc passes of this command on this round\'s kernels: '
                                     'FETCH_SIZE x2 + WRITE_SIZE); not measured by this run') if os.path.exists(PMC_TABLE) else None, launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),

@@ -39,7 +39,8 @@ enum mbx_epilogue {
     MBX_EPI_GELU  = 1, /* out2_t = gelu_erf(acc + bias); out_t = acc + bias if non-NULL   fc1 + nn.GELU (:80-81) */
     MBX_EPI_RESID = 2, /* out_f = resid + acc + bias                  proj / fc2 + residual (:241-249)     */
     MBX_EPI_TANH  = 3, /* out_f = tanh(acc + bias)                    pre_logits fc + Tanh (:294-297,354)  */
-    MBX_EPI_DGELU = 4  /* out_t = acc * gelu_erf'(aux_t)              backward of nn.GELU                  */
+    MBX_EPI_DGELU = 4, /* out_t = acc * gelu_erf'(aux_t)              backward of nn.GELU                  */
+    MBX_EPI_LNBWD = 5  /* internal to mbx_gemm_nt_lnbwd (LayerNorm backward as a GEMM epilogue); not accepted by mbx_gemm_nt */
 };
 
 enum mbx_attn_mode {
@@ -67,7 +68,7 @@ int mbx_embed_bwd(const float* dh, const float* x, const float* w, float* dw, fl
                   float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm, biased variance, eps inside sqrt; DSTformer.py:221-222,230-231,292)
- * x [M,C] f32 -> y [M,C] T, mean [M], rstd [M] */
+ * x [M,C] f32 -> y [M,C] T, mean [M], rstd [M].  gamma = beta = NULL: y = (x - mean) rstd (see "LayerNorm folded" below) */
 int mbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* y,
                       float* mean, float* rstd, int M, int C, int dtype, void* stream);
 /* dx = LN'(dy) [+ dres] [+ extra]  (f32);  dx_t = T copy of dx (or NULL);  dgamma, dbeta [C].
@@ -87,6 +88,37 @@ int mbx_gemm_nt(const void* a, const void* w, const float* bias, int epilogue, v
 size_t mbx_gemm_tn_ws(int M, int N, int K);
 int mbx_gemm_tn(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, int dtype,
                 void* ws, void* stream);
+
+/* ---- LayerNorm folded into the Linear it feeds (bf16 path) ---------------------------------------------------------------
+ * Every norm1 / norm2 of a Block feeds exactly one Linear (DSTformer.py:241-249 -> Attention.qkv :143 / MLP.fc1 :80):
+ *     Linear(LayerNorm(x)) = xhat . (W diag(gamma))^T + (b + W beta) = xhat . W'^T + b',   xhat = (x - mean) rstd.
+ * Forward: mbx_layernorm_fwd / mbx_fuse_ln_fwd with gamma = beta = NULL write xhat as the GEMM operand; the weights come from
+ * mbx_fold_norm_weights.  Backward: with rsum[n] = sum_k W'[n,k] the two row means of nn.LayerNorm's backward are row dots of
+ * dY with quantities the PRODUCER of dY holds,
+ *     c1[m] = mean_k dxhat = (1/C) sum_n dY[m,n] rsum[n],    c2[m] = mean_k dxhat xhat = (1/C) sum_n dY[m,n] (Y[m,n] - b'[n]),
+ * so mbx_attn_bwd_stats / mbx_gemm_nt_dgelu_stats emit them as partial sums, mbx_lnbwd_rowc finalises them and
+ * mbx_gemm_nt_lnbwd applies  dx = dres [+ extra] + rstd (dY . W' - c1 - xhat c2)  as the epilogue of the dX GEMM: no stand-alone
+ * LayerNorm-backward pass, no bf16 round trip of d(xn).  mbx_unfold_norm_grads turns the folded weight gradient into the
+ * gradients of W, gamma and beta.  (The final `norm` -> pre_logits path, :350-354, keeps the plain kernels.)
+ *
+ * mbx_fold_norm_weights: `desc` = n_desc records of 10 x int64 {w f32 [N,K], bias f32 [N] or 0, gamma f32 [K], beta f32 [K],
+ *   dst_n bf16 [N,K], dst_t bf16 [K,N] or 0, bias_f f32 [N], rsum f32 [N], N, K}; rsum sums the bf16-ROUNDED folded weights. */
+int mbx_fold_norm_weights(const int64_t* desc, int n_desc, int max_n, int max_k, void* stream);
+/* MBX_EPI_DGELU + part[M][N/64][2] f32 = per row and 64-column block { sum du rsum, sum du (aux_t - bias_f) } of the rounded
+ * output du.  bf16; N % 64 == 0, K % 64 == 0. */
+int mbx_gemm_nt_dgelu_stats(const void* a, const void* w, void* out_t, const void* aux_t, const float* bias_f,
+                            const float* rsum, float* part, int M, int N, int K, void* stream);
+/* rowc[M][4] f32 = {rstd, rstd c1, rstd c2, 0} from part[M][nb][2] (nb = 2 x heads, or N/64 column blocks) */
+int mbx_lnbwd_rowc(const float* part, int nb, const float* rstd, float* rowc, int M, int C, void* stream);
+/* dx[M,N] f32 = dres [+ extra] + rowc.x (a . w^T) - rowc.y - xhat rowc.z;  dx_t = bf16 copy of dx or NULL.
+ * a bf16 [M,K] (dY), w bf16 [N,K] (the transposed folded weight), xhat bf16 [M,N].  N % 8 == 0, K % 64 == 0. */
+int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat, const float* rowc, const float* dres,
+                      const float* extra, float* dx, void* dx_t, int M, int N, int K, void* stream);
+/* in place: dw[N,K] (= dY^T xhat, the folded weight gradient) <- gamma[k] dw[n,k] + db[n] beta[k];
+ * dgamma[k] = sum_n w[n,k] dw'[n,k];  dbeta[k] = sum_n w[n,k] db[n].  ws: >= mbx_unfold_norm_grads_ws(N,K) bytes. */
+size_t mbx_unfold_norm_grads_ws(int N, int K);
+int mbx_unfold_norm_grads(float* dw, const float* db, const float* w, const float* gamma, const float* beta,
+                          float* dgamma, float* dbeta, int N, int K, void* ws, void* stream);
 
 /* g = gelu_erf(u), T-typed, n % 4 == 0: rebuilds the MLP's post-activation from the saved pre-activation in the engine's
  * low-memory (recompute) mode (nn.GELU, DSTformer.py:70,80-81). */
@@ -114,6 +146,11 @@ int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, int J, int 
 /* dqkv [M,3C] T from do [M,C] T; probabilities are recomputed from q, k and lse. */
 int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T,
                  int J, int H, int hd, float scale, int mode, int dtype, void* stream);
+/* mbx_attn_bwd (bf16) + part[M][2H][2] f32 = per (token, head, role) { sum dqkv rsum, sum dqkv (qkv - bias_f) } of the rounded
+ * output over the head's q columns (role 0) and over its k and v columns (role 1) (LayerNorm folding, above; nb = 2H for
+ * mbx_lnbwd_rowc).  rsum, bias_f: f32 [3C].  part must be 16-byte aligned. */
+int mbx_attn_bwd_stats(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, const float* bias_f,
+                       const float* rsum, float* part, int B, int T, int J, int H, int hd, float scale, int mode, void* stream);
 
 /* ---- adaptive fusion of the two streams (DSTformer.py:343-349) -------------------------------
  * alpha = softmax(w . cat[x_st, x_ts] + b)  [M,2];  out = x_st*alpha0 + x_ts*alpha1.  w [2,2C], b [2]. */

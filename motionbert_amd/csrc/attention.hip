@@ -164,10 +164,9 @@ template <> struct MmaCols<float> {
 // kilobytes apart, so each load is a separate HBM/L2 round trip: they must overlap, not serialize).
 template <typename T, int HD>
 __device__ __forceinline__ void fill_two(char* dst0, const T* src0, size_t rs0, char* dst1, const T* src1, size_t rs1, int stride,
-                                         int L, int KP, int gtid, int gsize) {
+                                         int L, int KP, int gtid, int gsize, uint4 (&v0)[HD / AT<T>::EPC], uint4 (&v1)[HD / AT<T>::EPC]) {
     constexpr int CH = HD / AT<T>::EPC;   // 16-byte chunks per row; gsize * CH >= KP * CH for both launch shapes
     constexpr int NPT = CH;               // chunks per thread and tile (KP <= gsize)
-    uint4 v0[NPT], v1[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int idx = gtid + i * gsize, row = idx / CH, ch = idx % CH;
@@ -186,6 +185,12 @@ __device__ __forceinline__ void fill_two(char* dst0, const T* src0, size_t rs0, 
             *reinterpret_cast<uint4*>(dst1 + (size_t)row * stride + ch * 16) = v1[i];
         }
     }
+}
+template <typename T, int HD>
+__device__ __forceinline__ void fill_two(char* dst0, const T* src0, size_t rs0, char* dst1, const T* src1, size_t rs1, int stride,
+                                         int L, int KP, int gtid, int gsize) {
+    uint4 v0[HD / AT<T>::EPC], v1[HD / AT<T>::EPC];
+    fill_two<T, HD>(dst0, src0, rs0, dst1, src1, rs1, stride, L, KP, gtid, gsize, v0, v1);
 }
 // store an accumulator pair/quad set: lane owns sequence element `row`, registers own d
 template <typename T, int HD>
@@ -483,6 +488,45 @@ __global__ __launch_bounds__(AttnBlockKV<SHARED>::THREADS, SHARED ? 2 : 1) void 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row dots for the folded LayerNorm backward (round 3; "LayerNorm folding" in elementwise.hip).  With `st_part` the bf16 backward
+// kernels also leave, per (token, head), part[m][h][role] = { sum d rsum, sum d (y - b') } with role 0 = the head's q columns
+// (d = dq, y = q) and role 1 = its k and v columns, d = the bf16-ROUNDED gradient being stored.  They are taken where the
+// gradient rows are staged for the copy-out: the lane that writes a row fragment of dq / dk / dv into the LDS tile of q / k / v
+// first reads the original values it is about to overwrite (same row, same columns, 8 bytes at a time) -- no extra pass, no
+// global re-read (a first version re-read q, k, v in the copy-out loop: +21 % / +28 % on the two kernels).  rsum / b' of the
+// head's 3 hd columns sit in LDS (`vec`: per tensor rsum[hd] then b'[hd]); every lane of a half-wave reads the same address.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__device__ __forceinline__ void store_rowfrag_dot(bf16_t* row, const f32x16_t (&acc)[HD / 32], int g, const float* vec, float& p1,
+                                                  float& p2) {
+#pragma unroll
+    for (int df = 0; df < HD / 32; ++df)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d0 = df * 32 + 8 * q + 4 * g;
+            const uint2 o = *reinterpret_cast<const uint2*>(row + d0);
+            const float4 rs = *reinterpret_cast<const float4*>(vec + d0), bs = *reinterpret_cast<const float4*>(vec + HD + d0);
+            const uint32_t lo = pack_bf2(acc[df][4 * q], acc[df][4 * q + 1]), hi = pack_bf2(acc[df][4 * q + 2], acc[df][4 * q + 3]);
+            const float d0f = __uint_as_float(lo << 16), d1f = __uint_as_float(lo & 0xffff0000u);
+            const float d2f = __uint_as_float(hi << 16), d3f = __uint_as_float(hi & 0xffff0000u);
+            const float y0 = __uint_as_float(o.x << 16), y1 = __uint_as_float(o.x & 0xffff0000u);
+            const float y2 = __uint_as_float(o.y << 16), y3 = __uint_as_float(o.y & 0xffff0000u);
+            p1 = fmaf(d0f, rs.x, fmaf(d1f, rs.y, fmaf(d2f, rs.z, fmaf(d3f, rs.w, p1))));
+            p2 = fmaf(d0f, y0 - bs.x, fmaf(d1f, y1 - bs.y, fmaf(d2f, y2 - bs.z, fmaf(d3f, y3 - bs.w, p2))));
+            *reinterpret_cast<uint2*>(row + d0) = make_uint2(lo, hi);
+        }
+}
+// vec[j][0 .. HD) = rsum[j C + h HD + d], vec[j][HD .. 2 HD) = bias_f[j C + h HD + d], j = q, k, v
+template <int HD>
+__device__ __forceinline__ void fill_stat_vec(float* vec, const float* __restrict__ rsum, const float* __restrict__ bias, int C, int h,
+                                              int gtid, int gsize) {
+    for (int idx = gtid; idx < 6 * HD; idx += gsize) {
+        const int j = idx / (2 * HD), rem = idx % (2 * HD), d = rem % HD;
+        vec[idx] = (rem < HD ? rsum : bias)[j * C + h * HD + d];
+    }
+}
+
 // ================================================================================================
 // backward for short sequences (L <= 32: every spatial problem), dQ, dK and dV in ONE kernel.
 // One problem per wave, four per workgroup; Q, K, V and dO are staged once in wave-private LDS tiles and
@@ -493,11 +537,12 @@ template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                              const T* __restrict__ d_o, const float* __restrict__ lse,
                                                              T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
-                                                             int nprob) {
+                                                             int nprob, const float* __restrict__ st_bias,
+                                                             const float* __restrict__ st_rsum, float* __restrict__ st_part) {
     constexpr int KP = 32;
     constexpr int RSTR = rm_stride<T>(HD);
     constexpr int TILE = KP * RSTR;
-    constexpr int PER = 4 * TILE + 2 * KP * 4;
+    constexpr int PER = 4 * TILE + 2 * KP * 4 + 6 * HD * 4;      // four tiles, lse / delta, the row-dot vectors (stats variant)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, i = lane & 31;
     const int C = H * HD, C3 = 3 * C;
@@ -511,12 +556,15 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
     char* dot_ = vt + TILE;
     float* lse_s = reinterpret_cast<float*>(dot_ + TILE);
     float* del_s = lse_s + KP;
+    float* vec = del_s + KP;
+    const bool stats = sizeof(T) == 2 && st_part != nullptr;      // wave-uniform
     const size_t rstride = (size_t)P.tstep * C3, ostride = (size_t)P.tstep * C;
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     const T* dobase = d_o + P.tok0 * C + (size_t)P.h * HD;
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
     fill_two<T, HD>(qt, qbase, rstride, kt, qbase + C, rstride, RSTR, P.L, KP, lane, 64);
     fill_two<T, HD>(vt, qbase + 2 * C, rstride, dot_, dobase, ostride, RSTR, P.L, KP, lane, 64);
+    if (stats) fill_stat_vec<HD>(vec, st_rsum, st_bias, C, P.h, lane, 64);
     {   // per-row statistics: lse and delta = sum_d dO * O (one row per lane, all loads in flight together)
         const int q = lane;
         if (q < KP) {
@@ -570,8 +618,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
         BReg<T, HD> kreg, vreg;
         kreg.load(reinterpret_cast<const T*>(kt + (size_t)i * RSTR), g, true);
         vreg.load(reinterpret_cast<const T*>(vt + (size_t)i * RSTR), g, true);
-        // the K tile is dead from here on (wave-private, LDS operations of one wave execute in order): it stages dQ
-        store_rowfrag<T, HD>(reinterpret_cast<T*>(kt + (size_t)i * RSTR), dq, 1.0f, g);
+        // the K tile is dead from here on (wave-private, LDS operations of one wave execute in order): it stages dQ -- unless
+        // the row dots are wanted: then dQ waits in registers and every gradient is staged over ITS OWN original at the end
+        if (!stats) store_rowfrag<T, HD>(reinterpret_cast<T*>(kt + (size_t)i * RSTR), dq, 1.0f, g);
         f32x16_t sf, dp, dk[HD / 32], dv[HD / 32];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sf[r] = 0.f; dp[r] = 0.f; }
@@ -600,20 +649,39 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
             MmaCols<T>::run(dot_, RSTR, df * 32, 0, sf, lane, dv[df]);
             MmaCols<T>::run(qt, RSTR, df * 32, 0, dp, lane, dk[df]);
         }
-        // V tile (dead since vreg was loaded) stages dK, the Q tile (dead after the last product above) stages dV
-        store_rowfrag<T, HD>(reinterpret_cast<T*>(vt + (size_t)i * RSTR), dk, 1.0f, g);
-        store_rowfrag<T, HD>(reinterpret_cast<T*>(qt + (size_t)i * RSTR), dv, 1.0f, g);
+        if constexpr (sizeof(T) == 2) {
+            if (stats) {
+                // all four tiles are dead as operands; q, k, v are still intact: dq -> Q tile, dk -> K tile, dv -> V tile, each
+                // lane taking the two dots of its row fragment with the values it overwrites
+                float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+                store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(qt + (size_t)i * RSTR), dq, g, vec, a1, a2);
+                store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(kt + (size_t)i * RSTR), dk, g, vec + 2 * HD, b1, b2);
+                store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(vt + (size_t)i * RSTR), dv, g, vec + 4 * HD, b1, b2);
+                a1 = wave_halves<WaveAdd>(a1); a2 = wave_halves<WaveAdd>(a2);      // the two column halves of a row: lanes i, i + 32
+                b1 = wave_halves<WaveAdd>(b1); b2 = wave_halves<WaveAdd>(b2);
+                if (rvalid && g == 0)
+                    *reinterpret_cast<float4*>(st_part + (tok * H + P.h) * 4) = make_float4(a1, a2, b1, b2);
+            }
+        }
+        if (!stats) {
+            // V tile (dead since vreg was loaded) stages dK, the Q tile (dead after the last product above) stages dV
+            store_rowfrag<T, HD>(reinterpret_cast<T*>(vt + (size_t)i * RSTR), dk, 1.0f, g);
+            store_rowfrag<T, HD>(reinterpret_cast<T*>(qt + (size_t)i * RSTR), dv, 1.0f, g);
+        }
     }
     // ---- copy out: eight lanes per 16-byte-chunked row, whole row segments per store instruction (the accumulator layout
     // stored directly touches 32 rows x 16 bytes per instruction) ----
     if (pvalid) {
         constexpr int CH = HD * (int)sizeof(T) / 16;
         T* ob = dqkv + P.tok0 * C3 + (size_t)P.h * HD;
+        const char* sa = stats ? qt : kt;      // where dq, dk, dv were staged (see above)
+        const char* sb = stats ? kt : vt;
+        const char* sc = stats ? vt : qt;
         for (int idx = lane; idx < P.L * CH; idx += 64) {
             const int r = idx / CH, ch = idx % CH, off = r * RSTR + ch * 16;
-            const uint4 a = *reinterpret_cast<const uint4*>(kt + off);
-            const uint4 b = *reinterpret_cast<const uint4*>(vt + off);
-            const uint4 c = *reinterpret_cast<const uint4*>(qt + off);
+            const uint4 a = *reinterpret_cast<const uint4*>(sa + off);
+            const uint4 b = *reinterpret_cast<const uint4*>(sb + off);
+            const uint4 c = *reinterpret_cast<const uint4*>(sc + off);
             T* dst = ob + (size_t)r * rstride + ch * (16 / (int)sizeof(T));
             *reinterpret_cast<uint4*>(dst) = a;
             *reinterpret_cast<uint4*>(dst + C) = b;
@@ -634,6 +702,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
 // Both roles run concurrently on every SIMD (two waves of each), so the MFMA chain of one hides the exp / pack VALU work
 // of the other.  No masks, as in the two-kernel form: padded rows of all four tiles are zero and invalid lanes never store.
 // ================================================================================================
+__device__ __forceinline__ bf16_t* qt_row(char* tile, int row, int stride) { return reinterpret_cast<bf16_t*>(tile + (size_t)row * stride); }
 template <int HD>
 __device__ __forceinline__ void mma_rows_ldsb(const char* tile, int stride, int row0, const char* brow, int lane, f32x16_t& acc) {
     const char* p = tile + (size_t)(row0 + (lane & 31)) * stride + (lane >> 5) * 16;
@@ -649,7 +718,8 @@ template <int HD>
 __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                  const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                  bf16_t* __restrict__ dqkv, int Tn, int J, int H, float scale,
-                                                                 int mode, int nprob, int KP) {
+                                                                 int mode, int nprob, int KP, const float* __restrict__ st_bias,
+                                                                 const float* __restrict__ st_rsum, float* __restrict__ st_part) {
     typedef bf16_t T;
     constexpr int RSTR = rm_stride<T>(HD), CH = HD / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -663,10 +733,12 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
     char* dot_ = vt + TB;
     float* lse_s = reinterpret_cast<float*>(dot_ + TB);
     float* del_s = lse_s + KP;
+    float* vec = del_s + KP;                 // 6 HD floats behind the statistics (row-dot vectors, stats variant)
     const size_t rstride = (size_t)P.tstep * C3, ostride = (size_t)P.tstep * C;
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     const T* dobase = d_o + P.tok0 * C + (size_t)P.h * HD;
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
+    if (st_part) fill_stat_vec<HD>(vec, st_rsum, st_bias, C, P.h, tid, 1024);
 
     // ---- stage the four tiles: 16-byte chunks, all loads of a pass in flight before the first LDS store ----
     for (int i0 = tid; i0 < KP * CH; i0 += 2048) {
@@ -787,7 +859,19 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
     asm volatile("" : "+v"(tid2));         // indices for the epilogue are re-derived here, not carried through the loops (128-VGPR budget)
     const int g2 = (tid2 >> 5) & 1, row2 = blk * 32 + (tid2 & 31);
     if (blk < nfr) {
-        if (wave < 8) {
+        if (st_part) {      // wave-uniform: each gradient row fragment goes over its own original, whose row dots it takes first
+            float p1 = 0.f, p2 = 0.f;
+            if (wave < 8) {
+                store_rowfrag_dot<HD>(qt_row(qt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), g2, vec, p1, p2);
+            } else {
+                store_rowfrag_dot<HD>(qt_row(kt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), g2, vec + 2 * HD, p1, p2);
+                store_rowfrag_dot<HD>(qt_row(vt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[HD / 32]), g2, vec + 4 * HD, p1, p2);
+            }
+            p1 = wave_halves<WaveAdd>(p1);
+            p2 = wave_halves<WaveAdd>(p2);
+            if (g2 == 0 && row2 < P.L)
+                *reinterpret_cast<float2*>(st_part + ((P.tok0 + (size_t)row2 * P.tstep) * H + P.h) * 4 + (wave < 8 ? 0 : 2)) = make_float2(p1, p2);
+        } else if (wave < 8) {
             store_rowfrag<T, HD>(reinterpret_cast<T*>(qt + (size_t)row2 * RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), 1.0f, g2);
         } else {
             store_rowfrag<T, HD>(reinterpret_cast<T*>(kt + (size_t)row2 * RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), 1.0f, g2);
@@ -893,8 +977,9 @@ static int launch_bwd(const void* qkv, const void* o, const void* d_o, const flo
     return 0;
 }
 
-extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
-                            int H, int hd, float scale, int mode, int dtype, void* stream) {
+static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
+                         int H, int hd, float scale, int mode, int dtype, void* stream, const float* st_bias, const float* st_rsum,
+                         float* st_part) {
     MBX_CHECK_ARG(qkv && o && d_o && lse && dqkv, "attn_bwd: null pointer");
     if (check_attn_args("attn_bwd", B, T, J, H, hd, mode, dtype)) return 1;
     const int L = mode == MBX_ATTN_SPATIAL ? J : T;
@@ -904,14 +989,14 @@ extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, con
     hipStream_t s = (hipStream_t)stream;
 #ifndef MBX_ATTN_BWD_TWO_KERNELS      // A/B builds only (tools/build_variants.py): force the dQ + dK/dV kernel pair
     if (shared && dtype == MBX_BF16) {
-        const size_t shm = (size_t)4 * KP * rm_stride<bf16_t>(hd) + 2 * KP * 4;
+        const size_t shm = (size_t)4 * KP * rm_stride<bf16_t>(hd) + 2 * KP * 4 + 6 * hd * 4;
         if (shm <= 160 * 1024) {
 #define MBX_BWD_FUSED(HDV)                                                                                            \
     do {                                                                                                              \
         auto k = attn_bwd_fused_kernel<HDV>;                                                                          \
         if (set_lds(k, shm, "attn_bwd_fused")) return 1;                                                              \
         hipLaunchKernelGGL(k, dim3(nprob), dim3(1024), shm, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse, \
-                           (bf16_t*)dqkv, T, J, H, scale, mode, nprob, KP);                                           \
+                           (bf16_t*)dqkv, T, J, H, scale, mode, nprob, KP, st_bias, st_rsum, st_part);                \
         MBX_LAUNCH_CHECK("attn_bwd_fused");                                                                           \
         return 0;                                                                                                     \
     } while (0)
@@ -923,11 +1008,11 @@ extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, con
     if (!shared) {
 #define MBX_BWD_SMALL(TT, HDV)                                                                                        \
     do {                                                                                                              \
-        const size_t shm = (size_t)4 * (4 * 32 * rm_stride<TT>(HDV) + 2 * 32 * 4);                                    \
+        const size_t shm = (size_t)4 * (4 * 32 * rm_stride<TT>(HDV) + 2 * 32 * 4 + 6 * HDV * 4);                      \
         auto k = attn_bwd_small_kernel<TT, HDV>;                                                                      \
         if (set_lds(k, shm, "attn_bwd_small")) return 1;                                                              \
         hipLaunchKernelGGL(k, dim3((nprob + 3) / 4), dim3(256), shm, s, (const TT*)qkv, (const TT*)o, (const TT*)d_o, lse, \
-                           (TT*)dqkv, T, J, H, scale, mode, nprob);                                                   \
+                           (TT*)dqkv, T, J, H, scale, mode, nprob, st_bias, st_rsum, st_part);                        \
         MBX_LAUNCH_CHECK("attn_bwd_small");                                                                           \
         return 0;                                                                                                     \
     } while (0)
@@ -935,10 +1020,24 @@ extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, con
         else { if (hd == 64) MBX_BWD_SMALL(float, 64); else MBX_BWD_SMALL(float, 32); }
 #undef MBX_BWD_SMALL
     }
+    MBX_CHECK_ARG(!st_part, "attn_bwd_stats: this shape runs the two-kernel backward, which has no row-dot output");
 #define MBX_BWD(TT, HDV)                                                                                             \
     (shared ? launch_bwd<TT, HDV, true>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s)                   \
             : launch_bwd<TT, HDV, false>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s))
     if (dtype == MBX_BF16) return hd == 64 ? MBX_BWD(bf16_t, 64) : MBX_BWD(bf16_t, 32);
     return hd == 64 ? MBX_BWD(float, 64) : MBX_BWD(float, 32);
 #undef MBX_BWD
+}
+
+extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
+                            int H, int hd, float scale, int mode, int dtype, void* stream) {
+    return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, dtype, stream, nullptr, nullptr, nullptr);
+}
+// mbx_attn_bwd (bf16) + part[M][2H][2] = { sum dqkv rsum, sum dqkv (qkv - bias_f) } per (token, head, q | k+v columns); rsum, bias_f [3C] f32
+extern "C" int mbx_attn_bwd_stats(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, const float* bias_f,
+                                  const float* rsum, float* part, int B, int T, int J, int H, int hd, float scale, int mode,
+                                  void* stream) {
+    MBX_CHECK_ARG(bias_f && rsum && part, "attn_bwd_stats: null pointer");
+    MBX_CHECK_ARG((reinterpret_cast<uintptr_t>(part) & 15) == 0, "attn_bwd_stats: part must be 16-byte aligned");
+    return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, MBX_BF16, stream, bias_f, rsum, part);
 }

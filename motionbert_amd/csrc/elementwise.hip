@@ -529,7 +529,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const int c = ROW_C(k);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { g[k][i] = 0.f; bt[k][i] = 0.f; }
-        if (FULL || c < C) { load4<float>(gamma + c, g[k]); load4<float>(beta + c, bt[k]); }
+        if (gamma == nullptr) {     // plain normalisation (the affine part lives in the consumer's folded weights)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[k][i] = 1.f;
+        } else if (FULL || c < C) { load4<float>(gamma + c, g[k]); load4<float>(beta + c, bt[k]); }
     }
     const float invC = 1.0f / (float)C;
     const int step = gridDim.x * 4;
@@ -547,7 +550,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                          mean, rstd, M, C))
 extern "C" int mbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
                                  float* rstd, int M, int C, int dtype, void* stream) {
-    MBX_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    MBX_CHECK_ARG(x && y && mean && rstd, "layernorm_fwd: null pointer");
+    MBX_CHECK_ARG((gamma && beta) || (!gamma && !beta), "layernorm_fwd: gamma and beta come together (both NULL = plain normalisation)");
     MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "layernorm_fwd: bad shape M=%d C=%d", M, C);
     MBX_CHECK_ARG(dtype == MBX_BF16 || dtype == MBX_F32, "layernorm_fwd: unknown dtype %d", dtype);
     const int grid = clamp_grid((M + 3) / 4, LN_BLOCKS);
@@ -706,6 +710,159 @@ extern "C" int mbx_layernorm_bwd(const void* dy, const float* x, const float* me
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm folding (round 3, bf16 path).  A LayerNorm that only feeds one Linear (every norm1 / norm2 of a Block:
+// DSTformer.py:241-249 -> Attention.qkv :143 / MLP.fc1 :80) is split into the plain normalisation xhat = (x - mean) rstd,
+// which the LayerNorm kernel writes as the GEMM operand, and its affine part, which moves into the Linear:
+//     y = (xhat g + b_ln) W^T + b = xhat (W diag g)^T + (b + W b_ln) = xhat W'^T + b'.
+// What that buys is in BACKWARD: with s[n] = sum_k W'[n,k],
+//     c1[m] = mean_k dxhat[m,k]           = (1/C) sum_n dY[m,n] s[n]
+//     c2[m] = mean_k dxhat[m,k] xhat[m,k] = (1/C) sum_n dY[m,n] (Y[m,n] - b'[n])        (Y - b' = xhat W'^T)
+// are row dots over quantities the kernel that PRODUCES dY already holds (attention backward: dqkv and qkv; GELU' epilogue:
+// du and u), so the LayerNorm backward  dx = dres + rstd (dxhat - c1 - xhat c2)  needs no row reduction of its own and runs
+// as the epilogue of the dX GEMM (mbx_gemm_nt_lnbwd): the stand-alone LayerNorm-backward pass (16 B per residual element,
+// 40 launches, 12 % of the round-2 step) and the bf16 round trip of d(xn) disappear.  The parameter gradients follow from the
+// folded weight gradient dW' = dY^T xhat without touching the tokens:
+//     dW[n,k] = g[k] dW'[n,k] + db'[n] b_ln[k],   dg[k] = sum_n W[n,k] dW'[n,k],   db_ln[k] = sum_n W[n,k] db'[n],   db = db'.
+// ------------------------------------------------------------------------------------------------
+// descriptor record (10 x int64): {w f32 [N,K], bias f32 [N] or 0, gamma [K], beta [K], dst_n bf16 [N,K], dst_t bf16 [K,N] or 0,
+//                                  bias_f f32 [N], rsum f32 [N], N, K}
+__global__ __launch_bounds__(256) void fold_weights_kernel(const int64_t* __restrict__ desc) {
+    __shared__ float tile[32][33];
+    const int64_t* d = desc + (size_t)blockIdx.y * 10;
+    const float* src = reinterpret_cast<const float*>(d[0]);
+    const float* gam = reinterpret_cast<const float*>(d[2]);
+    bf16_t* dst_n = reinterpret_cast<bf16_t*>(d[4]);
+    bf16_t* dst_t = reinterpret_cast<bf16_t*>(d[5]);
+    const int N = (int)d[8], K = (int)d[9];
+    const int tk = (K + 31) / 32, tn = (N + 31) / 32;
+    if ((int)blockIdx.x >= tk * tn) return;
+    const int n0 = (blockIdx.x / tk) * 32, k0 = (blockIdx.x % tk) * 32;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const float gk = k0 + cx < K ? gam[k0 + cx] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ry + 8 * i;
+        float v = 0.f;
+        if (n0 + r < N && k0 + cx < K) {
+            v = src[(size_t)(n0 + r) * K + k0 + cx] * gk;
+            dst_n[(size_t)(n0 + r) * K + k0 + cx] = f2bf(v);
+        }
+        tile[r][cx] = v;
+    }
+    __syncthreads();
+    if (dst_t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ry + 8 * i;  // k index within the tile
+            if (k0 + r < K && n0 + cx < N) dst_t[(size_t)(k0 + r) * N + n0 + cx] = f2bf(tile[cx][r]);
+        }
+    }
+}
+// one wave per output row n: bias_f[n] = bias[n] + sum_k w[n,k] beta[k];  rsum[n] = sum_k float(bf16(w[n,k] gamma[k]))
+// (the ROUNDED folded weights: c1 must be the row mean of what the dX GEMM actually accumulates)
+__global__ __launch_bounds__(256) void fold_rows_kernel(const int64_t* __restrict__ desc) {
+    const int64_t* d = desc + (size_t)blockIdx.y * 10;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    const float* bias = reinterpret_cast<const float*>(d[1]);
+    const float* gam = reinterpret_cast<const float*>(d[2]);
+    const float* bet = reinterpret_cast<const float*>(d[3]);
+    float* bias_f = reinterpret_cast<float*>(d[6]);
+    float* rsum = reinterpret_cast<float*>(d[7]);
+    const int N = (int)d[8], K = (int)d[9];
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float sb = 0.f, sr = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = w[(size_t)n * K + k];
+        sb = fmaf(wv, bet[k], sb);
+        sr += bf2f(f2bf(wv * gam[k]));
+    }
+    sb = wave_sum(sb);
+    sr = wave_sum(sr);
+    if (lane == 0) { bias_f[n] = (bias ? bias[n] : 0.f) + sb; rsum[n] = sr; }
+}
+extern "C" int mbx_fold_norm_weights(const int64_t* desc, int n_desc, int max_n, int max_k, void* stream) {
+    MBX_CHECK_ARG(desc && n_desc > 0 && max_n > 0 && max_k > 0, "fold_norm_weights: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fold_weights_kernel, dim3(((max_n + 31) / 32) * ((max_k + 31) / 32), n_desc), dim3(256), 0, s, desc);
+    MBX_LAUNCH_CHECK("fold_weights");
+    hipLaunchKernelGGL(fold_rows_kernel, dim3((max_n + 3) / 4, n_desc), dim3(256), 0, s, desc);
+    MBX_LAUNCH_CHECK("fold_rows");
+    return 0;
+}
+
+// rowc[m] = {rstd, rstd c1, rstd c2, 0} from the producer's partial row dots part[m][nb][2] = {sum dY s, sum dY (Y - b')}
+// over nb column blocks (heads for the attention backward, 64-column blocks for the GELU' epilogue); fixed summation order.
+__global__ __launch_bounds__(256) void lnbwd_rowc_kernel(const float* __restrict__ part, int nb, const float* __restrict__ rstd,
+                                                         float4* __restrict__ rowc, int M, float invC) {
+    // (8 / nb2) rows per 8-lane group would complicate the indexing for little: one row per FOUR lanes, float2 per lane per step
+    const int m = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    float p1 = 0.f, p2 = 0.f;
+    if (m < M) {
+        const float2* pr = reinterpret_cast<const float2*>(part) + (size_t)m * nb;
+        for (int b = sub; b < nb; b += 4) { const float2 v = pr[b]; p1 += v.x; p2 += v.y; }
+    }
+    p1 += dpp_mov<0xB1>(p1, p1); p2 += dpp_mov<0xB1>(p2, p2);    // quad_perm [1,0,3,2]
+    p1 += dpp_mov<0x4E>(p1, p1); p2 += dpp_mov<0x4E>(p2, p2);    // quad_perm [2,3,0,1]
+    if (m < M && sub == 0) {
+        const float rs = rstd[m];
+        rowc[m] = make_float4(rs, rs * p1 * invC, rs * p2 * invC, 0.f);
+    }
+}
+extern "C" int mbx_lnbwd_rowc(const float* part, int nb, const float* rstd, float* rowc, int M, int C, void* stream) {
+    MBX_CHECK_ARG(part && rstd && rowc && nb > 0 && M > 0 && C > 0, "lnbwd_rowc: bad arguments");
+    hipLaunchKernelGGL(lnbwd_rowc_kernel, dim3((M + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nb, rstd,
+                       reinterpret_cast<float4*>(rowc), M, 1.0f / (float)C);
+    MBX_LAUNCH_CHECK("lnbwd_rowc");
+    return 0;
+}
+
+// parameter gradients of a folded (LayerNorm -> Linear) pair from the folded weight gradient, in place:
+//   dw[n,k] <- gamma[k] dw[n,k] + db[n] beta[k];   partial dgamma[k] = sum_n w[n,k] dw'[n,k];   partial dbeta[k] = sum_n w[n,k] db[n]
+// block = 64 rows (n) x 64 columns (k); partial row layout [dgamma K | dbeta K] per 64-row block, folded by colsum.
+__global__ __launch_bounds__(256) void unfold_norm_grads_kernel(float* __restrict__ dw, const float* __restrict__ db,
+                                                                const float* __restrict__ w, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ part, int N, int K) {
+    __shared__ float red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + tx, nb0 = blockIdx.y * 64;
+    float ag = 0.f, ab = 0.f;
+    if (k < K) {
+        const float g = gamma[k], bt = beta[k];
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int n = nb0 + ty + 4 * i;
+            if (n < N) {
+                const size_t o = (size_t)n * K + k;
+                const float dwp = dw[o], wv = w[o], dbn = db[n];
+                ag = fmaf(wv, dwp, ag);
+                ab = fmaf(wv, dbn, ab);
+                dw[o] = fmaf(g, dwp, dbn * bt);
+            }
+        }
+    }
+    red[0][ty][tx] = ag;
+    red[1][ty][tx] = ab;
+    __syncthreads();
+    if (ty == 0 && k < K) {
+        float* pr = part + (size_t)blockIdx.y * 2 * K;
+        pr[k] = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+        pr[K + k] = (red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx]);
+    }
+}
+extern "C" size_t mbx_unfold_norm_grads_ws(int N, int K) { return (size_t)((N + 63) / 64) * 2 * K * sizeof(float); }
+extern "C" int mbx_unfold_norm_grads(float* dw, const float* db, const float* w, const float* gamma, const float* beta,
+                                     float* dgamma, float* dbeta, int N, int K, void* ws, void* stream) {
+    MBX_CHECK_ARG(dw && db && w && gamma && beta && dgamma && dbeta && ws, "unfold_norm_grads: null pointer");
+    MBX_CHECK_ARG(N > 0 && K > 0, "unfold_norm_grads: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (N + 63) / 64;
+    hipLaunchKernelGGL(unfold_norm_grads_kernel, dim3((K + 63) / 64, nblk), dim3(256), 0, s, dw, db, w, gamma, beta, (float*)ws, N, K);
+    MBX_LAUNCH_CHECK("unfold_norm_grads");
+    return launch_colsum2((const float*)ws, nblk, 2 * K, 0, 2 * K, dgamma, dbeta, K, s);
+}
+
+// ------------------------------------------------------------------------------------------------
 // adaptive fusion forward
 // ------------------------------------------------------------------------------------------------
 template <int VPL>
@@ -834,8 +991,8 @@ __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(const float* __restric
         ROW_LOOP(k) {
             const int c = ROW_C(k);
             if (c < C) {
-                float gg[4], bt[4], o[4];
-                load4<float>(g1 + c, gg); load4<float>(b1 + c, bt);
+                float gg[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+                if (g1) { load4<float>(g1 + c, gg); load4<float>(b1 + c, bt); }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = fmaf(a[k][i] * rs, gg[i], bt[i]);
                 store4<T>(xn1 + (size_t)row * C + c, o);
@@ -853,7 +1010,8 @@ __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(const float* __restric
 extern "C" int mbx_fuse_ln_fwd(const float* x_st, const float* x_ts, const float* w, const float* b, float* out, float* alpha,
                                const float* g1, const float* b1, void* xn1, const float* g2, const float* b2, void* xn2, float eps,
                                float* mean, float* rstd, int M, int C, int dtype, void* stream) {
-    MBX_CHECK_ARG(x_st && x_ts && w && b && out && alpha && g1 && b1 && xn1 && mean && rstd, "fuse_ln_fwd: null pointer");
+    MBX_CHECK_ARG(x_st && x_ts && w && b && out && alpha && xn1 && mean && rstd, "fuse_ln_fwd: null pointer");
+    MBX_CHECK_ARG((g1 && b1) || (!g1 && !b1 && !xn2), "fuse_ln_fwd: g1 / b1 come together (both NULL = one plain normalisation, no second output)");
     MBX_CHECK_ARG((g2 && b2 && xn2) || (!g2 && !b2 && !xn2), "fuse_ln_fwd: the second LayerNorm needs gamma, beta and an output (or none of them)");
     MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "fuse_ln_fwd: bad shape");
     MBX_CHECK_ARG(dtype == MBX_BF16 || dtype == MBX_F32, "fuse_ln_fwd: unknown dtype %d", dtype);

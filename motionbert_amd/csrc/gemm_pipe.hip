@@ -71,7 +71,16 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
                                                               const float* __restrict__ bias, bf16_t* __restrict__ out_t,
                                                               bf16_t* __restrict__ out2_t, float* __restrict__ out_f,
                                                               const float* __restrict__ resid, const bf16_t* __restrict__ aux,
-                                                              int M, int N, int K, int ntn, int dbg, long long* trace) {
+                                                              int M, int N, int K, int ntn, const float4* __restrict__ rowc,
+                                                              const float* __restrict__ extra
+#ifdef MBX_DIAG
+                                                              , int dbg, long long* trace
+#endif
+                                                              ) {
+#ifndef MBX_DIAG
+    constexpr int dbg = 0;                 // ablation switches and cycle stamps exist in diagnostic builds only
+    constexpr long long* trace = nullptr;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 stages x 24 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lid = xcd_remap2(blockIdx.x, gridDim.x);
@@ -168,6 +177,69 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
     if (dbg & 4) return;
     __builtin_amdgcn_s_barrier();                           // all waves are done reading the last stage
     char* er = smem + wave * (64 * EROW);                   // 9 KiB per wave, 72 KiB per workgroup
+    if constexpr (EPI == MBX_EPI_LNBWD) {
+        // LayerNorm backward as the epilogue of the dX GEMM ("LayerNorm folding", elementwise.hip): acc = d(xhat),
+        //   dx = dres [+ extra] + rstd acc - rstd c1 - xhat rstd c2,   rowc[m] = {rstd, rstd c1, rstd c2, -}.
+        // Staging: 32 rows x 64 columns fp32 per pass (pitch 272 B, 8.5 KiB of the wave's 9 KiB), walked with eight lanes per row,
+        // eight columns per lane: one instruction = 8 rows x 256 B (fp32 in / out) or 8 rows x 128 B (bf16 xhat in, dx_t out).
+        constexpr int EP = 64 * 4 + 16;
+        const int rr8 = lane >> 3, cc = (lane & 7) * 8;
+        const int n = n0 + wn * 64 + cc, nc = min(n, N - 8);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int mb = m0 + wm * 64 + tm * 32;
+            // the inputs of pass p+1 are requested before pass p is computed (clamped addresses; invalid lanes never store)
+            float4 dy0[2], dy1[2], rc[2];
+            uint4 xh[2];
+#define LNB_LOAD(slot_, p_)                                                                         \
+            do {                                                                                    \
+                const size_t mo_ = (size_t)min(mb + (p_) * 8 + rr8, M - 1);                         \
+                rc[slot_] = rowc[mo_];                                                              \
+                dy0[slot_] = *reinterpret_cast<const float4*>(resid + mo_ * N + nc);                \
+                dy1[slot_] = *reinterpret_cast<const float4*>(resid + mo_ * N + nc + 4);            \
+                xh[slot_] = *reinterpret_cast<const uint4*>(aux + mo_ * N + nc);                    \
+            } while (0)
+            LNB_LOAD(0, 0);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(er + i * EP + (tn * 32 + 8 * q + 4 * g) * 4) =
+                        make_float4(acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p + 1 < 4) LNB_LOAD((p + 1) & 1, p + 1);
+                const int rl = p * 8 + rr8, m = mb + rl, sl = p & 1;
+                const float4 a0 = *reinterpret_cast<const float4*>(er + rl * EP + cc * 4);
+                const float4 a1 = *reinterpret_cast<const float4*>(er + rl * EP + cc * 4 + 16);
+                if (m < M && n < N) {
+                    const size_t o = (size_t)m * N + n;
+                    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const float dv[8] = {dy0[sl].x, dy0[sl].y, dy0[sl].z, dy0[sl].w, dy1[sl].x, dy1[sl].y, dy1[sl].z, dy1[sl].w};
+                    const uint32_t xw[4] = {xh[sl].x, xh[sl].y, xh[sl].z, xh[sl].w};
+                    const float rs = rc[sl].x, k1 = rc[sl].y, k2 = rc[sl].z;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+                        v[2 * e] = dv[2 * e] + fmaf(rs, av[2 * e], -fmaf(x0, k2, k1));
+                        v[2 * e + 1] = dv[2 * e + 1] + fmaf(rs, av[2 * e + 1], -fmaf(x1, k2, k1));
+                    }
+                    if (extra) {
+                        const float4 e0 = *reinterpret_cast<const float4*>(extra + o), e1 = *reinterpret_cast<const float4*>(extra + o + 4);
+                        v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w;
+                        v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
+                    }
+                    *reinterpret_cast<float4*>(out_f + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(out_f + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    if (out_t)
+                        *reinterpret_cast<uint4*>(out_t + o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                }
+            }
+#undef LNB_LOAD
+        }
+        return;
+    }
     const int ec = (lane & 7) * 4, erow0 = lane >> 3;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
@@ -381,16 +453,27 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
 }
 // GELU' epilogue (second input stream `aux`): fp32 staging as in nt_epilogue, but each lane owns 8 columns: 16-byte
 // aux load, 16-byte store, one instruction = 8 rows x 128 B.
+// Round 3: with `st_part` the epilogue also leaves, per row and 64-column block, the two row dots the folded LayerNorm backward
+// needs (see "LayerNorm folding" in elementwise.hip): part[m][n / 64] = { sum_n du s[n], sum_n du (u - b'[n]) } over the
+// block's columns, du = the bf16-ROUNDED output (what the dX GEMM will read).  Eight lanes share a row: three DPP steps.
 template <int NTN>
 __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char* er, bf16_t* __restrict__ out_t,
                                                   const bf16_t* __restrict__ aux, int M, int N, int row_base, int col_base,
-                                                  int lane) {
+                                                  int lane, const float* __restrict__ st_bias = nullptr,
+                                                  const float* __restrict__ st_rsum = nullptr, float* __restrict__ st_part = nullptr) {
     const int i = lane & 31, g = lane >> 5;
     constexpr int EROW = 64 * 4 + 16;
     const int rr = lane >> 3, cc = (lane & 7) * 8;
 #pragma unroll
     for (int h = 0; h < NTN / 2; ++h) {
         const int n = col_base + h * 64 + cc;
+        float sv[8], bv[8];
+        if (st_part) {
+            load4<float>(st_rsum + min(n, N - 8), *reinterpret_cast<float (*)[4]>(&sv[0]));
+            load4<float>(st_rsum + min(n, N - 8) + 4, *reinterpret_cast<float (*)[4]>(&sv[4]));
+            load4<float>(st_bias + min(n, N - 8), *reinterpret_cast<float (*)[4]>(&bv[0]));
+            load4<float>(st_bias + min(n, N - 8) + 4, *reinterpret_cast<float (*)[4]>(&bv[4]));
+        }
         // the aux (pre-activation) stream runs one 32-row block ahead of the staging: its HBM latency is paid under the LDS
         // round trip of the previous block (clamped addresses, unconditional: out-of-range lanes never store)
         const bf16_t* auxc = aux + min(n, N - 8);
@@ -416,7 +499,9 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
                 const int rl = p * 8 + rr, m = row_base + tm * 32 + rl;
                 const float4 a0 = *reinterpret_cast<const float4*>(er + rl * EROW + cc * 4);
                 const float4 a1 = *reinterpret_cast<const float4*>(er + rl * EROW + cc * 4 + 16);
-                if (m < M && n < N) {
+                float q1 = 0.f, q2 = 0.f;
+                const bool ok = m < M && n < N;
+                if (ok) {
                     const size_t o = (size_t)m * N + n;
                     const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                     const uint32_t uw[4] = {ua[tm & 1][p].x, ua[tm & 1][p].y, ua[tm & 1][p].z, ua[tm & 1][p].w};
@@ -425,8 +510,20 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
                     for (int e = 0; e < 4; ++e) {
                         const float u0 = __uint_as_float(uw[e] << 16), u1 = __uint_as_float(uw[e] & 0xffff0000u);
                         r[e] = pack_bf2(v[2 * e] * gelu_fast_grad(u0), v[2 * e + 1] * gelu_fast_grad(u1));
+                        if (st_part) {
+                            const float d0 = __uint_as_float(r[e] << 16), d1 = __uint_as_float(r[e] & 0xffff0000u);
+                            q1 = fmaf(d0, sv[2 * e], fmaf(d1, sv[2 * e + 1], q1));
+                            q2 = fmaf(d0, u0 - bv[2 * e], fmaf(d1, u1 - bv[2 * e + 1], q2));
+                        }
                     }
                     *reinterpret_cast<uint4*>(out_t + o) = make_uint4(r[0], r[1], r[2], r[3]);
+                }
+                if (st_part) {     // wave-uniform; every lane takes part in the cross-lane steps
+                    q1 += dpp_mov<0xB1>(q1, q1); q2 += dpp_mov<0xB1>(q2, q2);      // quad_perm [1,0,3,2]
+                    q1 += dpp_mov<0x4E>(q1, q1); q2 += dpp_mov<0x4E>(q2, q2);      // quad_perm [2,3,0,1]
+                    q1 += dpp_mov<0x141>(q1, q1); q2 += dpp_mov<0x141>(q2, q2);    // row_half_mirror: the other quad of the 8-lane group
+                    if (ok && (lane & 7) == 0)
+                        *reinterpret_cast<float2*>(st_part + ((size_t)m * (N >> 6) + (n >> 6)) * 2) = make_float2(q1, q2);
                 }
             }
         }
@@ -438,7 +535,8 @@ template <int EPI, typename TO = bf16_t>
 __device__ __forceinline__ void nt256_epilogue(f32x16_t (&acc)[2][4], char* smem, const float* __restrict__ bias,
                                                TO* __restrict__ out_t, TO* __restrict__ out2_t, float* __restrict__ out_f,
                                                const float* __restrict__ resid, const TO* __restrict__ aux, int M, int N, int m0,
-                                               int n0, int wave, int lane) {
+                                               int n0, int wave, int lane, const float* __restrict__ st_bias = nullptr,
+                                               const float* __restrict__ st_rsum = nullptr, float* __restrict__ st_part = nullptr) {
     __builtin_amdgcn_s_barrier();   // every wave is done with the k-loop's LDS stages
     char* er = smem + wave * Q_EPI_WAVE_BYTES;
     const int row_base = m0 + (wave >> 2) * 128, col_base = n0 + (wave & 3) * 64;
@@ -451,7 +549,7 @@ __device__ __forceinline__ void nt256_epilogue(f32x16_t (&acc)[2][4], char* smem
             nt_epilogue_bf16<EPI, 2, false>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane);
     }
     else if constexpr (EPI == MBX_EPI_DGELU)
-        nt_epilogue_dgelu<2>(acc, er, out_t, aux, M, N, row_base, col_base, lane);
+        nt_epilogue_dgelu<2>(acc, er, out_t, aux, M, N, row_base, col_base, lane, st_bias, st_rsum, st_part);
     else
         nt_epilogue<EPI, 2, TO>(acc, er, bias, out_t, out2_t, out_f, resid, aux, M, N, row_base, col_base, lane);
 }
@@ -560,7 +658,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
                                                                const float* __restrict__ bias, typename std::conditional<X3, float, bf16_t>::type* __restrict__ out_t,
                                                                typename std::conditional<X3, float, bf16_t>::type* __restrict__ out2_t, float* __restrict__ out_f,
                                                                const float* __restrict__ resid, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ aux,
-                                                               int M, int N, int K, int ntn, long long* trace) {
+                                                               int M, int N, int K, int ntn, long long* trace,
+                                                               const float* __restrict__ st_bias, const float* __restrict__ st_rsum,
+                                                               float* __restrict__ st_part) {
     typedef typename std::conditional<X3, float, bf16_t>::type TO;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 stages x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -696,7 +796,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
 #undef PSTAMP
     if (!trailing) __builtin_amdgcn_s_barrier();   // pairs with the trailing group's last phase
 
-    nt256_epilogue<EPI, TO>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane);
+    nt256_epilogue<EPI, TO>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane, st_bias, st_rsum, st_part);
 #ifdef MBX_DIAG
     if (trace != nullptr && blockIdx.x == 3000 && (tid == 0 || tid == 256)) {
         long long* const tr2 = trace + (tid == 256 ? 2048 : 0);
@@ -715,7 +815,8 @@ static int set_lds_attr(K kernel, size_t bytes, const char* who) {
 }
 
 static int launch_nt256(const void* a, const void* w, const float* bias, int epi, void* out_t, void* out2_t, float* out_f,
-                        const float* resid, const void* aux, int M, int N, int K, hipStream_t s) {
+                        const float* resid, const void* aux, int M, int N, int K, hipStream_t s, const float* st_bias = nullptr,
+                        const float* st_rsum = nullptr, float* st_part = nullptr) {
     const int ntn = (N + Q_BN - 1) / Q_BN, ntm = (M + Q_BM - 1) / Q_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
     const size_t shm = Q_NSTAGE * Q_STAGE;
@@ -739,7 +840,8 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
         if (set_lds_attr(gemm_nt_pp256_kernel<E>, shm, "gemm_nt_pp256")) return 1;                                    \
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w,        \
                            (const bf16_t*)nullptr, (const bf16_t*)nullptr, bias,                                      \
-                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn, pptrace); \
+                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn, pptrace, \
+                           st_bias, st_rsum, st_part);                                                                \
         break;
     switch (epi) {
         MBX_Q_CASE(MBX_EPI_STORE)
@@ -767,7 +869,7 @@ int mbx_launch_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_hi, 
         if (set_lds_attr(gemm_nt_pp256_kernel<E, true>, shm, "gemm_nt_x3")) return 1;                                 \
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E, true>), grid, block, shm, s, (const bf16_t*)a_hi, (const bf16_t*)w_hi, \
                            (const bf16_t*)a_lo, (const bf16_t*)w_lo, bias, out_t, out2_t, out_f, resid, aux, M, N, K, ntn, \
-                           (long long*)nullptr);                                                                      \
+                           (long long*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);       \
         break;
     switch (epi) {
         MBX_X3_CASE(MBX_EPI_STORE)
@@ -791,17 +893,19 @@ int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int
     const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
     const size_t shm = P_NSTAGE * P_STAGE;
-    static const int dbg = mbx_env_int("MBX_DBG", 0);
 #ifdef MBX_DIAG
+    static const int dbg = mbx_env_int("MBX_DBG", 0);
     static long long* const trace = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
+#define MBX_NTP_DIAG_ARGS , dbg, trace
 #else
-    long long* const trace = nullptr;
+#define MBX_NTP_DIAG_ARGS
 #endif
 #define MBX_NTP_CASE(E)                                                                                               \
     case E:                                                                                                           \
         if (set_lds_attr(gemm_nt_pipe_kernel<E>, shm, "gemm_nt_pipe")) return 1;                                      \
         hipLaunchKernelGGL((gemm_nt_pipe_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w, bias,   \
-                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn, dbg, trace);          \
+                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn,           \
+                           (const float4*)nullptr, (const float*)nullptr MBX_NTP_DIAG_ARGS);                          \
         break;
     switch (epi) {
         MBX_NTP_CASE(MBX_EPI_STORE)
@@ -813,6 +917,38 @@ int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int
     }
 #undef MBX_NTP_CASE
     MBX_LAUNCH_CHECK("gemm_nt_pipe");
+    return 0;
+}
+
+// ---- round 3: the two GEMM entries of the folded LayerNorm backward (see "LayerNorm folding" in elementwise.hip) --------------
+// du = (dy . W2) * gelu'(u)  (the DGELU epilogue) + the row dots part[M][N/64][2] of du with rsum and (u - bias_f)
+extern "C" int mbx_gemm_nt_dgelu_stats(const void* a, const void* w, void* out_t, const void* aux_t, const float* bias_f,
+                                       const float* rsum, float* part, int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(a && w && out_t && aux_t && bias_f && rsum && part, "gemm_nt_dgelu_stats: null pointer");
+    MBX_CHECK_ARG(M > 0 && N > 0 && N % 64 == 0 && K > 0 && K % 64 == 0, "gemm_nt_dgelu_stats: bad shape M=%d N=%d K=%d (N %% 64, K %% 64)", M, N, K);
+    return launch_nt256(a, w, nullptr, MBX_EPI_DGELU, out_t, nullptr, nullptr, nullptr, aux_t, M, N, K, (hipStream_t)stream, bias_f, rsum, part);
+}
+// dx = dres [+ extra] + rstd (dy . Wt' - c1 - xhat c2)  with rowc[m] = {rstd, rstd c1, rstd c2, -};  dx_t = bf16 copy (or NULL)
+extern "C" int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat, const float* rowc, const float* dres,
+                                 const float* extra, float* dx, void* dx_t, int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(a && w && xhat && rowc && dres && dx, "gemm_nt_lnbwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && K > 0 && K % 64 == 0, "gemm_nt_lnbwd: bad shape M=%d N=%d K=%d (N %% 8, K %% 64)", M, N, K);
+    MBX_CHECK_ARG((reinterpret_cast<uintptr_t>(rowc) & 15) == 0, "gemm_nt_lnbwd: rowc must be 16-byte aligned");
+    const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
+    const size_t shm = P_NSTAGE * P_STAGE;
+    hipStream_t s = (hipStream_t)stream;
+#ifdef MBX_DIAG
+    static const int dbg = mbx_env_int("MBX_DBG", 0);
+#endif
+    if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_LNBWD>, shm, "gemm_nt_lnbwd")) return 1;
+    hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_LNBWD>), dim3((unsigned)ntn * ntm), dim3(512), shm, s, (const bf16_t*)a, (const bf16_t*)w,
+                       (const float*)nullptr, (bf16_t*)dx_t, (bf16_t*)nullptr, dx, dres, (const bf16_t*)xhat, M, N, K, ntn,
+                       reinterpret_cast<const float4*>(rowc), extra
+#ifdef MBX_DIAG
+                       , dbg, (long long*)nullptr
+#endif
+                       );
+    MBX_LAUNCH_CHECK("gemm_nt_lnbwd");
     return 0;
 }
 

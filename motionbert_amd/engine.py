@@ -89,6 +89,18 @@ def linear_names(cfg: ModelCfg) -> List[str]:
     return names
 
 
+def folded_pairs(cfg: ModelCfg) -> List[tuple]:
+    """(linear, norm) pairs whose LayerNorm is folded into the Linear it feeds (bf16 path): every norm1 -> qkv and norm2 -> fc1
+    of every Block (DSTformer.py:241-249).  The final `norm` -> pre_logits.fc keeps the plain kernels."""
+    pairs = []
+    for stream in ('blocks_st', 'blocks_ts'):
+        for i in range(cfg.depth):
+            for sfx in ('s', 't'):
+                pairs.append((f'{stream}.{i}.attn_{sfx}.qkv', f'{stream}.{i}.norm1_{sfx}'))
+                pairs.append((f'{stream}.{i}.mlp_{sfx}.fc1', f'{stream}.{i}.norm2_{sfx}'))
+    return pairs
+
+
 def grad_bucket(name: str, depth: int) -> int:
     """Bucket of a parameter in backward completion order: tail first, then the levels from the
     last to the first, the embedding last.  The flat gradient buffer is laid out bucket by bucket."""
@@ -131,6 +143,15 @@ class Engine:
         # default: 137.0 -> 136.0 ms per step at 64 clips, but the operands stay alive until that stream catches up
         # (record_stream), which at 256 clips (231 GiB resident) sends the allocator into retries: 421 -> 37 clips/s.
         self.wgrad_async = os.environ.get('MBX_WGRAD_STREAM', '0') == '1'
+        # LayerNorm folding (round 3, bf16 path; include/mbx.h "LayerNorm folded into the Linear it feeds"): the LayerNorm kernels
+        # write the plain normalisation xhat, the affine part lives in the qkv / fc1 weights, and the LayerNorm BACKWARD runs as the
+        # epilogue of the dX GEMM from row dots the attention-backward / GELU' kernels emit -- 40 LayerNorm-backward launches and the
+        # saved fp32 sub-layer inputs disappear.  Off with dropout (the masks sit between the producer and the row dots), in the
+        # fp32-class modes (bf16 kernels only), or by request (model.fold_ln = False / MBX_FOLD_LN=0: the A/B switch).
+        self.fold = (os.environ.get('MBX_FOLD_LN', '1') == '1' and not x3 and drop_seed is None and
+                     bool(getattr(ops, 'can_fold', lambda *_: False)(tdtype, cfg)))
+        self.Bf: Dict[str, torch.Tensor] = {}
+        self.Rs: Dict[str, torch.Tensor] = {}
 
     def _streams(self):
         """(main, side) streams for the dual-stream schedule, or (None, None)."""
@@ -228,6 +249,21 @@ class Engine:
         """GEMM operand form of a T-typed tensor: itself, or its (hi, lo) bf16 planes in bf16x3 mode."""
         return self.ops.split(t) if self.x3 else t
 
+    def prepare_weights(self, need_grad: bool):
+        """T-typed copies of every Linear weight (and their transposes when a backward follows); with LayerNorm folding the
+        qkv / fc1 weights are W diag(gamma) and come with their folded bias and row sums."""
+        cfg, ops, P = self.cfg, self.ops, self.P
+        if self.fold:
+            pairs = folded_pairs(cfg)
+            folded = {l for l, _ in pairs}
+            self.Wn, self.Wt = ops.prep_weights(P, [n for n in linear_names(cfg) if n not in folded], self.T, need_grad)
+            fn, ft, self.Bf, self.Rs = ops.fold_norm_weights(P, pairs, need_grad, self.T)
+            self.Wn.update(fn)
+            self.Wt.update(ft)
+        else:
+            self.Wn, self.Wt = (ops.prep_weights(P, linear_names(cfg), self.T, need_grad, x3=True) if self.x3 else
+                                ops.prep_weights(P, linear_names(cfg), self.T, need_grad))
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, return_rep, need_grad: bool, tta_perm=None):
         """`return_rep`: False (pose output), True (representation, DSTformer.py:360) or a tuple ('pool', persons, p, seed):
@@ -242,8 +278,7 @@ class Engine:
             B = 2 * B
         M, C = B * T * J, cfg.C
         self.B, self.Tlen, self.M = B, T, M
-        self.Wn, self.Wt = (ops.prep_weights(P, linear_names(cfg), self.T, need_grad, x3=True) if self.x3 else
-                            ops.prep_weights(P, linear_names(cfg), self.T, need_grad))
+        self.prepare_weights(need_grad)
         h = self._f(M, C)
         if tta_perm is not None:
             ops.embed_fwd_tta(x, tta_perm, P['joints_embed.weight'], P['joints_embed.bias'], P['pos_embed'], P['temp_embed'], h, B // 2, T, J)
@@ -274,14 +309,20 @@ class Engine:
                 last = i + 1 == cfg.depth
                 n1 = 'norm' if last else f"blocks_st.{i + 1}.{ORDER['st'][0][1]}"
                 n2 = None if last else f"blocks_ts.{i + 1}.{ORDER['ts'][0][1]}"
-                xn1, xn2 = self._t(M, C), (None if last else self._t(M, C))
-                ops.fuse_ln_fwd(x_st, x_ts, P[f'ts_attn.{i}.weight'], P[f'ts_attn.{i}.bias'], hn, alpha,
-                                P[n1 + '.weight'], P[n1 + '.bias'], xn1, P[n2 + '.weight'] if n2 else None, P[n2 + '.bias'] if n2 else None, xn2,
-                                cfg.eps, mean, rstd)
-                if last:
-                    ln_tail = (xn1, mean, rstd)
+                if self.fold and not last:      # ONE plain normalisation serves both blocks of the next level
+                    xn1 = self._t(M, C)
+                    ops.fuse_ln_fwd(x_st, x_ts, P[f'ts_attn.{i}.weight'], P[f'ts_attn.{i}.bias'], hn, alpha,
+                                    None, None, xn1, None, None, None, cfg.eps, mean, rstd)
+                    ln_st = ln_ts = (xn1, mean, rstd)
                 else:
-                    ln_st, ln_ts = (xn1, mean, rstd), (xn2, mean, rstd)
+                    xn1, xn2 = self._t(M, C), (None if last else self._t(M, C))
+                    ops.fuse_ln_fwd(x_st, x_ts, P[f'ts_attn.{i}.weight'], P[f'ts_attn.{i}.bias'], hn, alpha,
+                                    P[n1 + '.weight'], P[n1 + '.bias'], xn1, P[n2 + '.weight'] if n2 else None, P[n2 + '.bias'] if n2 else None, xn2,
+                                    cfg.eps, mean, rstd)
+                    if last:
+                        ln_tail = (xn1, mean, rstd)
+                    else:
+                        ln_st, ln_ts = (xn1, mean, rstd), (xn2, mean, rstd)
             elif cfg.att_fuse:
                 alpha = self._f(M, 2)
                 ops.fuse_fwd(x_st, x_ts, P[f'ts_attn.{i}.weight'], P[f'ts_attn.{i}.bias'], hn, alpha)
@@ -337,10 +378,14 @@ class Engine:
             xn, mean, rstd = ln
         else:
             xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
-            ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
+            if self.fold:
+                ops.layernorm_fwd(x, None, None, cfg.eps, xn, mean, rstd)
+            else:
+                ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
         xn = self._mm(xn)
         qkv = self._t(M, 3 * C)
-        ops.gemm_nt(xn, self.Wn[f'{pre}.{attn}.qkv'], self._bias(f'{pre}.{attn}.qkv'), EPI_STORE, out_t=qkv)
+        ops.gemm_nt(xn, self.Wn[f'{pre}.{attn}.qkv'], self.Bf[f'{pre}.{attn}.qkv'] if self.fold else self._bias(f'{pre}.{attn}.qkv'),
+                    EPI_STORE, out_t=qkv)
         dm, tape = self._drops(pre, sub), None
         if dm is not None and dm[5] > 0:
             o, tape = self._torch_attention(qkv, mode, dm[5], dm[6])
@@ -352,17 +397,24 @@ class Engine:
         ops.gemm_nt(self._mm(o), self.Wn[f'{pre}.{attn}.proj'], P[f'{pre}.{attn}.proj.bias'], EPI_RESID, resid=x, out_f=y)
         if dm is not None and (dm[0] > 0 or dm[3] > 0):      # proj_drop + DropPath on the branch (DSTformer.py:148-149,241)
             ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])
-        sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, qkv=qkv, o=o, lse=lse, dm=dm, tape=tape) if need_grad else None
+        if self.fold:      # backward needs xhat and rstd only: the fp32 sub-layer input is not kept
+            sv = dict(x=None, mean=None, rstd=rstd, xn=xn, qkv=qkv, o=o, lse=lse, dm=dm, tape=tape) if need_grad else None
+        else:
+            sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, qkv=qkv, o=o, lse=lse, dm=dm, tape=tape) if need_grad else None
         return y, sv
 
     def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1):
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C = self.M, cfg.C
         xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
-        ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
+        if self.fold:
+            ops.layernorm_fwd(x, None, None, cfg.eps, xn, mean, rstd)
+        else:
+            ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
         xn = self._mm(xn)
         u, g = (self._t(M, cfg.hidden) if need_grad else None), self._t(M, cfg.hidden)   # u only feeds GELU' in backward
-        ops.gemm_nt(xn, self.Wn[f'{pre}.{mlp}.fc1'], P[f'{pre}.{mlp}.fc1.bias'], EPI_GELU, out_t=u, out2_t=g)
+        ops.gemm_nt(xn, self.Wn[f'{pre}.{mlp}.fc1'], self.Bf[f'{pre}.{mlp}.fc1'] if self.fold else P[f'{pre}.{mlp}.fc1.bias'],
+                    EPI_GELU, out_t=u, out2_t=g)
         dm = self._drops(pre, sub)
         if dm is not None and dm[0] > 0:                      # MLP drop after the activation (DSTformer.py:82)
             ops.dropout(g, g, dm[0], dm[2])
@@ -371,7 +423,10 @@ class Engine:
         ops.gemm_nt(g, self.Wn[f'{pre}.{mlp}.fc2'], P[f'{pre}.{mlp}.fc2.bias'], EPI_RESID, resid=x, out_f=y)
         if dm is not None and (dm[0] > 0 or dm[3] > 0):      # MLP drop after fc2 + DropPath (DSTformer.py:84,242)
             ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])
-        sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, u=u, g=None if self.recompute else g, dm=dm) if need_grad else None
+        if self.fold:
+            sv = dict(x=None, mean=None, rstd=rstd, xn=xn, u=u, g=None if self.recompute else g, dm=dm) if need_grad else None
+        else:
+            sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, u=u, g=None if self.recompute else g, dm=dm) if need_grad else None
         return y, sv
 
     # ----------------------------------------------------------------- backward
@@ -482,6 +537,13 @@ class Engine:
         self._tn(dy_t, self._mm(sv['o']), G[f'{pre}.{attn}.proj.weight'], G[f'{pre}.{attn}.proj.bias'])
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{attn}.proj'], None, EPI_STORE, out_t=do)
         dqkv = self._t(M, 3 * C)
+        if self.fold:
+            lin = f'{pre}.{attn}.qkv'
+            part = self._f(M, 2 * cfg.H, 2)       # per head: the q columns, the k + v columns
+            ops.attn_bwd_stats(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.Bf[lin], self.Rs[lin], part, self.B, self.Tlen, cfg.J, cfg.H,
+                               cfg.scale, mode)
+            del do
+            return self._fold_tail(dqkv, part, sv, lin, f'{pre}.{norm}', dy, extra, need_t)
         if sv.get('tape') is not None:                        # torch fallback of the attention core (attn_drop > 0)
             leaf, o32 = sv['tape']
             (dq32,) = torch.autograd.grad(o32, leaf, do.float())
@@ -501,6 +563,37 @@ class Engine:
             extra = extra()
         ops.layernorm_bwd(dxn, sv['x'], sv['mean'], sv['rstd'], P[f'{pre}.{norm}.weight'], dy, extra,
                           dx, dx_t, G[f'{pre}.{norm}.weight'], G[f'{pre}.{norm}.bias'])
+        return dx, dx_t
+
+    def _fold_tail(self, dY, part, sv, lin, norm, dy, extra, need_t):
+        """Folded (LayerNorm -> Linear) pair, backward from the Linear's output gradient dY and its row dots `part`: weight
+        gradient, then dx = dy [+ extra] + LayerNorm'(dY . W') as the epilogue of the dX GEMM, then the parameter gradients of
+        W, gamma and beta from the folded weight gradient."""
+        cfg, ops, P, G = self.cfg, self.ops, self.P, self.grads
+        M, C = self.M, cfg.C
+        rowc = self._f(M, 4)
+        ops.lnbwd_rowc(part, sv['rstd'], rowc, C)
+        db = G.get(lin + '.bias')
+        if db is None:                     # qkv_bias=False: the column sums of dY are still needed for d(beta)
+            db = self._f(dY.shape[1])
+        ws = self._wstream()
+        if ws is None:
+            ops.gemm_tn(dY, sv['xn'], G[lin + '.weight'], db)
+            ops.unfold_norm_grads(G[lin + '.weight'], db, P[lin + '.weight'], P[norm + '.weight'], P[norm + '.bias'],
+                                  G[norm + '.weight'], G[norm + '.bias'])
+        else:
+            ws.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ws):
+                ops.gemm_tn(dY, sv['xn'], G[lin + '.weight'], db)
+                ops.unfold_norm_grads(G[lin + '.weight'], db, P[lin + '.weight'], P[norm + '.weight'], P[norm + '.bias'],
+                                      G[norm + '.weight'], G[norm + '.bias'])
+            for t in (dY, sv['xn'], db):
+                t.record_stream(ws)
+        dx = self._f(M, C)
+        dx_t = self._t(M, C) if need_t else None
+        if callable(extra):      # dual-stream backward: the other block's input gradient, awaited only now
+            extra = extra()
+        ops.gemm_nt_lnbwd(dY, self.Wt[lin], sv['xn'], rowc, dy, extra, dx, dx_t)
         return dx, dx_t
 
     def _mlp_bwd(self, dy, dy_t, sv, pre, norm, mlp, extra, need_t):
@@ -524,6 +617,11 @@ class Engine:
             g = self._mm(g)
         self._tn(dy_t, g, G[f'{pre}.{mlp}.fc2.weight'], G[f'{pre}.{mlp}.fc2.bias'])
         del g
+        if self.fold:
+            lin = f'{pre}.{mlp}.fc1'
+            part = self._f(M, cfg.hidden // 64, 2)
+            ops.gemm_nt_dgelu_stats(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], du, sv['u'], self.Bf[lin], self.Rs[lin], part)
+            return self._fold_tail(du, part, sv, lin, f'{pre}.{norm}', dy, extra, need_t)
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], None, EPI_DGELU, out_t=du, aux_t=sv['u'])
         if dm is not None and dm[0] > 0:                      # backward of the drop after the activation (commutes with GELU')
             ops.dropout(du, du, dm[0], dm[2])

@@ -36,6 +36,12 @@ SIGNATURES = {
     'mbx_gemm_nt': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mbx_gemm_tn_ws': (_sz, [_i, _i, _i]),
     'mbx_gemm_tn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'mbx_fold_norm_weights': (_i, [_i64p, _i, _i, _i, _vp]),
+    'mbx_gemm_nt_dgelu_stats': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
+    'mbx_lnbwd_rowc': (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
+    'mbx_gemm_nt_lnbwd': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
+    'mbx_unfold_norm_grads_ws': (_sz, [_i, _i]),
+    'mbx_unfold_norm_grads': (_i, [_vp] * 7 + [_i, _i, _vp, _vp]),
     'mbx_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),
     'mbx_split_bf16': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'mbx_gemm_nt_x3': (_i, [_vp] * 5 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),
@@ -43,6 +49,7 @@ SIGNATURES = {
     'mbx_gemm_tn_x3': (_i, [_vp] * 6 + [_i, _i, _i, _vp, _vp]),
     'mbx_attn_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'mbx_attn_bwd': (_i, [_vp] * 5 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'mbx_attn_bwd_stats': (_i, [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
     'mbx_fuse_fwd': (_i, [_vp] * 6 + [_i, _i, _vp]),
     'mbx_fuse_ln_fwd': (_i, [_vp] * 12 + [_f] + [_vp] * 2 + [_i] * 3 + [_vp]),
     'mbx_fuse_bwd_ws': (_sz, [_i]),
@@ -162,6 +169,87 @@ class HipOps:
             if need_t:
                 Wt[n] = flat_t[off:off + N * K].view(K, N)
         return Wn, Wt
+
+    # ------------------------------------------------------------------ LayerNorm folding (bf16 path)
+    @staticmethod
+    def can_fold(tdtype, cfg) -> bool:
+        """The folded-LayerNorm kernels exist for bf16 operands; the GELU' row dots come per 64-column block."""
+        return tdtype == torch.bfloat16 and cfg.hidden % 64 == 0 and cfg.C % 8 == 0
+
+    def fold_norm_weights(self, P: Dict[str, torch.Tensor], pairs, need_t: bool, tdtype=torch.bfloat16):
+        """For every (linear, norm) pair: Wn[linear] = bf16(W diag(gamma)) [N,K], Wt[linear] = its transpose [K,N] (need_t),
+        Bf[linear] = b + W beta (fp32 [N]), Rs[linear] = row sums of the rounded folded weights (fp32 [N]).  One call, two launches."""
+        if tdtype != torch.bfloat16:
+            raise RuntimeError('libmbx: fold_norm_weights is a bf16 path')
+        ws = [P[l + '.weight'] for l, _ in pairs]
+        dev = ws[0].device
+        key = ('fold', tuple((w.data_ptr(), tuple(w.shape), P[n + '.weight'].data_ptr(), P[n + '.bias'].data_ptr(),
+                              0 if P.get(l + '.bias') is None else P[l + '.bias'].data_ptr()) for (l, n), w in zip(pairs, ws)), dev.index)
+        with self._lock:
+            ent = self._desc_cache.get(key)
+            if ent is None:
+                rows, offs, voffs, off, voff = [], [], [], 0, 0
+                for (l, n), w in zip(pairs, ws):
+                    N, K = w.shape
+                    b = P.get(l + '.bias')
+                    for t in (w, P[n + '.weight'], P[n + '.bias']) + ((b,) if b is not None else ()):
+                        if t.dtype != torch.float32 or not t.is_contiguous():
+                            raise RuntimeError('libmbx: parameters must be contiguous fp32')
+                    rows.append([w.data_ptr(), 0 if b is None else b.data_ptr(), P[n + '.weight'].data_ptr(), P[n + '.bias'].data_ptr(),
+                                 0, 0, 0, 0, N, K])
+                    offs.append(off)
+                    voffs.append(voff)
+                    off += N * K
+                    voff += N
+                if len(self._desc_cache) > 64:
+                    self._desc_cache.clear()
+                ent = dict(desc=torch.tensor(rows, dtype=torch.int64).to(dev), offs=(torch.tensor(offs, dtype=torch.int64) * 2).to(dev),
+                           voffs=(torch.tensor(voffs, dtype=torch.int64) * 4).to(dev), offs_host=offs, voffs_host=voffs, total=off,
+                           vtotal=voff, max_n=max(w.shape[0] for w in ws), max_k=max(w.shape[1] for w in ws))
+                self._desc_cache[key] = ent
+        desc = ent['desc'].clone()
+        flat_n = torch.empty(ent['total'], dtype=torch.bfloat16, device=dev)
+        flat_t = torch.empty(ent['total'], dtype=torch.bfloat16, device=dev) if need_t else None
+        flat_b = torch.empty(ent['vtotal'], dtype=torch.float32, device=dev)
+        flat_r = torch.empty(ent['vtotal'], dtype=torch.float32, device=dev)
+        desc[:, 4] = ent['offs'] + flat_n.data_ptr()
+        if need_t:
+            desc[:, 5] = ent['offs'] + flat_t.data_ptr()
+        desc[:, 6] = ent['voffs'] + flat_b.data_ptr()
+        desc[:, 7] = ent['voffs'] + flat_r.data_ptr()
+        self._ck(self.lib.mbx_fold_norm_weights(desc.data_ptr(), len(ws), ent['max_n'], ent['max_k'], self._stream()))
+        Wn, Wt, Bf, Rs = {}, {}, {}, {}
+        for (l, _), w, off, voff in zip(pairs, ws, ent['offs_host'], ent['voffs_host']):
+            N, K = w.shape
+            Wn[l] = flat_n[off:off + N * K].view(N, K)
+            if need_t:
+                Wt[l] = flat_t[off:off + N * K].view(K, N)
+            Bf[l], Rs[l] = flat_b[voff:voff + N], flat_r[voff:voff + N]
+        return Wn, Wt, Bf, Rs
+
+    def gemm_nt_dgelu_stats(self, a_t, w_t, out_t, aux_t, bias_f, rsum, part):
+        M, K = a_t.shape
+        N = w_t.shape[0]
+        self._ck(self.lib.mbx_gemm_nt_dgelu_stats(_p(a_t), _p(w_t), _p(out_t), _p(aux_t), _p(bias_f), _p(rsum), _p(part), M, N, K, self._stream()))
+
+    def attn_bwd_stats(self, qkv, o, do, lse, dqkv, bias_f, rsum, part, B, T, J, H, scale, mode):
+        hd = o.shape[-1] // H
+        self._ck(self.lib.mbx_attn_bwd_stats(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), _p(bias_f), _p(rsum), _p(part), B, T, J, H, hd,
+                                             float(scale), int(mode), self._stream()))
+
+    def lnbwd_rowc(self, part, rstd, rowc, C):
+        M, nb = part.shape[0], part.shape[1]
+        self._ck(self.lib.mbx_lnbwd_rowc(_p(part), nb, _p(rstd), _p(rowc), M, int(C), self._stream()))
+
+    def gemm_nt_lnbwd(self, a_t, w_t, xhat, rowc, dres, extra, dx, dx_t):
+        M, K = a_t.shape
+        N = w_t.shape[0]
+        self._ck(self.lib.mbx_gemm_nt_lnbwd(_p(a_t), _p(w_t), _p(xhat), _p(rowc), _p(dres), _p(extra), _p(dx), _p(dx_t), M, N, K, self._stream()))
+
+    def unfold_norm_grads(self, dw, db, w, gamma, beta, dgamma, dbeta):
+        N, K = dw.shape
+        ws = self._ws(('unf', N, K), self.lib.mbx_unfold_norm_grads_ws, N, K, device=dw.device)
+        self._ck(self.lib.mbx_unfold_norm_grads(_p(dw), _p(db), _p(w), _p(gamma), _p(beta), _p(dgamma), _p(dbeta), N, K, _p(ws), self._stream()))
 
     # ------------------------------------------------------------------ embedding
     def embed_fwd(self, x, w, b, pos, temp, h, B, T, J):

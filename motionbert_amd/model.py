@@ -119,9 +119,11 @@ class _DSTformerFn(torch.autograd.Function):
         grad_enabled, grad_sync = grad_sync
         need_grad = grad_enabled and any(ctx.needs_input_grad[6:])
         P = dict(zip(names, params))
+        precision, fold = (precision[:-3], False) if precision.endswith('+nf') else (precision, True)
         precision, recompute = (precision[:-2], True) if precision.endswith('+r') else (precision, False)
         eng = Engine(ops, cfg, P, _DTYPES[precision], x3=precision == 'bf16x3', drop_seed=drop_seed)
         eng.recompute = recompute
+        eng.fold = eng.fold and fold
         with _device_of(x):
             tta = None
             if isinstance(return_rep, tuple) and return_rep[0] == 'tta':
@@ -230,7 +232,7 @@ def run(ops, model, x, return_rep=False, grad_sync=None):
         drop_seed = getattr(model, '_drop_seed', None)
         if drop_seed is None:
             drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    return _DSTformerFn.apply(ops, cfg, names, (model.precision + ('+r' if getattr(model, 'recompute', False) else ''), drop_seed), return_rep, (torch.is_grad_enabled(), grad_sync), x, *params)
+    return _DSTformerFn.apply(ops, cfg, names, (model.precision + ('+r' if getattr(model, 'recompute', False) else '') + ('' if getattr(model, 'fold_ln', True) else '+nf'), drop_seed), return_rep, (torch.is_grad_enabled(), grad_sync), x, *params)
 
 
 class DSTformer(nn.Module):

@@ -49,6 +49,72 @@ class MockOps:
         Wt = {n: P[n + '.weight'].detach().t().to(tdtype).contiguous() for n in names} if need_t else {}
         return Wn, Wt
 
+    # LayerNorm folding (include/mbx.h "LayerNorm folded into the Linear it feeds") ---------------------------
+    @staticmethod
+    def can_fold(tdtype, cfg):
+        return cfg.hidden % 64 == 0
+
+    def fold_norm_weights(self, P, pairs, need_t, tdtype=torch.bfloat16):
+        """Wn = T(W diag(gamma)), Wt = its transpose, Bf = b + W beta, Rs = row sums of the ROUNDED folded weights."""
+        self._log('fold_norm_weights')
+        Wn, Wt, Bf, Rs = {}, {}, {}, {}
+        for lin, norm in pairs:
+            W, g, bt, b = P[lin + '.weight'].detach(), P[norm + '.weight'].detach(), P[norm + '.bias'].detach(), P.get(lin + '.bias')
+            Wf = (W * g[None, :]).to(tdtype)
+            Wn[lin] = Wf.contiguous()
+            if need_t:
+                Wt[lin] = Wf.t().contiguous()
+            Bf[lin] = W @ bt + (b.detach() if b is not None else 0.0)
+            Rs[lin] = Wf.float().sum(1)
+        return Wn, Wt, Bf, Rs
+
+    def gemm_nt_dgelu_stats(self, a_t, w_t, out_t, aux_t, bias_f, rsum, part):
+        """EPI_DGELU + part[m][n // 64] = { sum du rsum, sum du (u - bias_f) } over each 64-column block of the ROUNDED du."""
+        self._log(f'gemm_nt.{EPI_DGELU}.stats')
+        acc = a_t.float() @ w_t.float().t()
+        u = aux_t.float()
+        out_t.copy_((acc * _gelu_grad(u)).to(out_t.dtype))
+        d = out_t.float()
+        M, N = d.shape
+        part.copy_(torch.stack([(d * rsum).reshape(M, N // 64, 64).sum(-1), (d * (u - bias_f)).reshape(M, N // 64, 64).sum(-1)], -1))
+
+    def attn_bwd_stats(self, qkv, o, do, lse, dqkv, bias_f, rsum, part, B, T, J, H, scale, mode):
+        """attn_bwd + part[m][2 h + role] = { sum d rsum, sum d (qkv - bias_f) } of the rounded dqkv over the head's q columns
+        (role 0) and over its k and v columns (role 1)."""
+        self.attn_bwd(qkv, o, do, lse, dqkv, B, T, J, H, scale, mode)
+        self.calls[-1] += '.stats'
+        M = dqkv.shape[0]
+        d = dqkv.float().reshape(M, 3, H, -1)
+        y = (qkv.float() - bias_f).reshape(M, 3, H, -1)
+        t1, t2 = (d * rsum.reshape(1, 3, H, -1)).sum(3), (d * y).sum(3)            # [M, 3, H]
+        p1 = torch.stack([t1[:, 0], t1[:, 1] + t1[:, 2]], -1)                       # [M, H, role]
+        p2 = torch.stack([t2[:, 0], t2[:, 1] + t2[:, 2]], -1)
+        part.copy_(torch.stack([p1, p2], -1).reshape(part.shape))
+
+    def lnbwd_rowc(self, part, rstd, rowc, C):
+        """rowc[m] = {rstd, rstd c1, rstd c2, 0}, c = column-block sums of part / C."""
+        self._log('lnbwd_rowc')
+        c = part.sum(1) / C
+        rowc.copy_(torch.stack([rstd, rstd * c[:, 0], rstd * c[:, 1], torch.zeros_like(rstd)], -1))
+
+    def gemm_nt_lnbwd(self, a_t, w_t, xhat, rowc, dres, extra, dx, dx_t):
+        """dx = dres [+ extra] + rowc.x (a . w^T) - rowc.y - xhat rowc.z;  dx_t = T copy."""
+        self._log('gemm_nt.lnbwd')
+        acc = a_t.float() @ w_t.float().t()
+        r = dres + rowc[:, 0:1] * acc - rowc[:, 1:2] - xhat.float() * rowc[:, 2:3]
+        if extra is not None:
+            r = r + extra
+        dx.copy_(r)
+        if dx_t is not None:
+            dx_t.copy_(r.to(dx_t.dtype))
+
+    def unfold_norm_grads(self, dw, db, w, gamma, beta, dgamma, dbeta):
+        """in place: dw <- gamma[k] dw + db[n] beta[k];  dgamma = sum_n w dw';  dbeta = sum_n w db."""
+        self._log('unfold_norm_grads')
+        dgamma.copy_((w * dw).sum(0))
+        dbeta.copy_((w * db[:, None]).sum(0))
+        dw.copy_(dw * gamma[None, :] + db[:, None] * beta[None, :])
+
     # embedding -----------------------------------------------------------
     def embed_fwd(self, x, w, b, pos, temp, h, B, T, J):
         self._log('embed_fwd')
@@ -75,7 +141,8 @@ class MockOps:
         rs = torch.rsqrt(var + eps)
         mean.copy_(mu)
         rstd.copy_(rs)
-        y_t.copy_((((x - mu[:, None]) * rs[:, None]) * g + b).to(y_t.dtype))
+        xhat = (x - mu[:, None]) * rs[:, None]
+        y_t.copy_((xhat if g is None else xhat * g + b).to(y_t.dtype))     # g = b = None: plain normalisation
 
     def layernorm_bwd(self, dy_t, x, mean, rstd, g, dres, extra, dx, dx_t, dg, db):
         """dx = [dres] + [extra] + LN'(dy); dx_t = T copy of dx; dg, db reduced over rows."""

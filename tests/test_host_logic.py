@@ -20,12 +20,15 @@ def _load(model, z):
     assert not missing.missing_keys and not missing.unexpected_keys
 
 
+@pytest.mark.parametrize('fold', [True, False])
 @pytest.mark.parametrize('name', ['tiny_default', 'tiny_trained'])
-def test_engine_fp32_matches_reference_gradients(name):
+def test_engine_fp32_matches_reference_gradients(name, fold):
+    """Both backward formulations against the reference's autograd gradients: fold=True is the LayerNorm-folded sequencing
+    (LayerNorm backward as the dX GEMM's epilogue from the producers' row dots; the product's bf16 path), fold=False the plain one."""
     z, cfg = load_golden(name)
     model = build_model(cfg)
     _load(model, z)
-    model.precision = 'fp32'
+    model.precision, model.fold_ln = 'fp32', fold
     ops = MockOps()
     x = torch.from_numpy(z['x']).requires_grad_(True)
     out = M.run(ops, model, x)
@@ -38,9 +41,13 @@ def test_engine_fp32_matches_reference_gradients(name):
         assert rel_l2(p.grad.numpy(), z['g.' + n]) < 5e-5, n
     # one prep + the expected number of GEMM launches: per level 2 blocks x 4 sub-layers
     depth = cfg['depth']
-    assert ops.calls.count('prep_weights') == 1
+    assert ops.calls.count('prep_weights') == 1 and ops.calls.count('fold_norm_weights') == int(fold)
     assert ops.calls.count('gemm_tn') == 8 * 2 * depth + 1
-    assert ops.calls.count('attn_bwd.0') == ops.calls.count('attn_bwd.1') == 2 * depth
+    sfx = '.stats' if fold else ''
+    assert ops.calls.count('attn_bwd.0' + sfx) == ops.calls.count('attn_bwd.1' + sfx) == 2 * depth
+    # folded: the only stand-alone LayerNorm backward left is the final `norm`; every Block LayerNorm runs as a GEMM epilogue
+    assert ops.calls.count('layernorm_bwd') == (1 if fold else 8 * depth + 1)
+    assert ops.calls.count('gemm_nt.lnbwd') == ops.calls.count('unfold_norm_grads') == ops.calls.count('lnbwd_rowc') == (8 * depth if fold else 0)
 
 
 def test_engine_representation_path(golden_dir):
@@ -215,16 +222,18 @@ def test_dropout_and_droppath_match_the_reference_with_forced_masks():
         assert rel_l2(M.run(MockOps(), model, x.detach()).numpy(), z['out']) < 2e-6
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3', 'bf16'])
-def test_recompute_mode_rebuilds_what_it_does_not_save(precision):
+@pytest.mark.parametrize('precision,fold', [('fp32', False), ('bf16x3', False), ('bf16', False), ('fp32', True), ('bf16', True)])
+def test_recompute_mode_rebuilds_what_it_does_not_save(precision, fold):
     """model.recompute: LayerNorm outputs and MLP post-activations are rebuilt in backward.  fp32-class modes: bit-identical
-    gradients; bf16: the rebuilt GELU starts from the bf16-rounded pre-activation (bf16-level difference)."""
+    gradients; bf16: the rebuilt GELU starts from the bf16-rounded pre-activation (bf16-level difference).  With LayerNorm
+    folding the normalised operand (2 bytes) is what backward keeps INSTEAD of the fp32 sub-layer input (4 bytes), so only the
+    post-activations are rebuilt."""
     z, cfg = load_golden('tiny_trained')
     grads, calls = [], []
     for rc in (False, True):
         model = build_model(cfg)
         _load(model, z)
-        model.precision, model.recompute = precision, rc
+        model.precision, model.recompute, model.fold_ln = precision, rc, fold
         ops = MockOps()
         out = M.run(ops, model, torch.from_numpy(z['x']))
         (out * torch.from_numpy(z['cot'])).sum().backward()
@@ -232,7 +241,7 @@ def test_recompute_mode_rebuilds_what_it_does_not_save(precision):
         calls.append(ops.calls)
     depth = cfg['depth']
     # per level: 2 blocks x 4 sub-layers rebuild their LayerNorm output, 2 blocks x 2 MLPs their post-activation
-    assert calls[1].count('layernorm_fwd') == calls[0].count('layernorm_fwd') + 8 * depth and calls[1].count('gelu_fwd') == 4 * depth
+    assert calls[1].count('layernorm_fwd') == calls[0].count('layernorm_fwd') + (0 if fold else 8 * depth) and calls[1].count('gelu_fwd') == 4 * depth
     worst = max(float((grads[0][n] - grads[1][n]).norm() / grads[0][n].norm().clamp_min(1e-20)) for n in grads[0])
     assert worst == 0.0 if precision != 'bf16' else worst < 2e-2, worst
 
