@@ -104,11 +104,11 @@ int mbx_gemm_tn(const void* dy, const void* a, float* dw, float* db, int M, int 
  * mbx_fold_norm_weights: `desc` = n_desc records of 10 x int64 {w f32 [N,K], bias f32 [N] or 0, gamma f32 [K], beta f32 [K],
  *   dst_n bf16 [N,K], dst_t bf16 [K,N] or 0, bias_f f32 [N], rsum f32 [N], N, K}; rsum sums the bf16-ROUNDED folded weights. */
 int mbx_fold_norm_weights(const int64_t* desc, int n_desc, int max_n, int max_k, void* stream);
-/* MBX_EPI_DGELU + part[M][N/64][2] f32 = per row and 64-column block { sum du rsum, sum du (aux_t - bias_f) } of the rounded
- * output du.  bf16; N % 64 == 0, K % 64 == 0. */
+/* MBX_EPI_DGELU + part[N/64][M][2] f32 = per 64-column block and row { sum du rsum, sum du (aux_t - bias_f) } of the rounded
+ * output du (rsum, bias_f enter rounded to bf16: packed-bf16 dot products).  bf16; N % 64 == 0, K % 64 == 0. */
 int mbx_gemm_nt_dgelu_stats(const void* a, const void* w, void* out_t, const void* aux_t, const float* bias_f,
                             const float* rsum, float* part, int M, int N, int K, void* stream);
-/* rowc[M][4] f32 = {rstd, rstd c1, rstd c2, 0} from part[M][nb][2] (nb = 2 x heads, or N/64 column blocks) */
+/* rowc[M][4] f32 = {rstd, rstd c1, rstd c2, 0} from part[nb][M][2] (block-major; nb = 2 x heads, or N/64 column blocks) */
 int mbx_lnbwd_rowc(const float* part, int nb, const float* rstd, float* rowc, int M, int C, void* stream);
 /* dx[M,N] f32 = dres [+ extra] + rowc.x (a . w^T) - rowc.y - xhat rowc.z;  dx_t = bf16 copy of dx or NULL.
  * a bf16 [M,K] (dY), w bf16 [N,K] (the transposed folded weight), xhat bf16 [M,N].  N % 8 == 0, K % 64 == 0. */
@@ -146,9 +146,9 @@ int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, int J, int 
 /* dqkv [M,3C] T from do [M,C] T; probabilities are recomputed from q, k and lse. */
 int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T,
                  int J, int H, int hd, float scale, int mode, int dtype, void* stream);
-/* mbx_attn_bwd (bf16) + part[M][2H][2] f32 = per (token, head, role) { sum dqkv rsum, sum dqkv (qkv - bias_f) } of the rounded
+/* mbx_attn_bwd (bf16) + part[2H][M][2] f32 = per (head, role, token) { sum dqkv rsum, sum dqkv (qkv - bias_f) } of the rounded
  * output over the head's q columns (role 0) and over its k and v columns (role 1) (LayerNorm folding, above; nb = 2H for
- * mbx_lnbwd_rowc).  rsum, bias_f: f32 [3C].  part must be 16-byte aligned. */
+ * mbx_lnbwd_rowc; rsum, bias_f f32 [3C], entering rounded to bf16).  part must be 8-byte aligned. */
 int mbx_attn_bwd_stats(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, const float* bias_f,
                        const float* rsum, float* part, int B, int T, int J, int H, int hd, float scale, int mode, void* stream);
 

@@ -490,40 +490,41 @@ __global__ __launch_bounds__(AttnBlockKV<SHARED>::THREADS, SHARED ? 2 : 1) void 
 
 // ------------------------------------------------------------------------------------------------
 // Row dots for the folded LayerNorm backward (round 3; "LayerNorm folding" in elementwise.hip).  With `st_part` the bf16 backward
-// kernels also leave, per (token, head), part[m][h][role] = { sum d rsum, sum d (y - b') } with role 0 = the head's q columns
+// kernels also leave, per (token, head), part[2 h + role][m] = { sum d rsum, sum d (y - b') } with role 0 = the head's q columns
 // (d = dq, y = q) and role 1 = its k and v columns, d = the bf16-ROUNDED gradient being stored.  They are taken where the
 // gradient rows are staged for the copy-out: the lane that writes a row fragment of dq / dk / dv into the LDS tile of q / k / v
 // first reads the original values it is about to overwrite (same row, same columns, 8 bytes at a time) -- no extra pass, no
-// global re-read (a first version re-read q, k, v in the copy-out loop: +21 % / +28 % on the two kernels).  rsum / b' of the
-// head's 3 hd columns sit in LDS (`vec`: per tensor rsum[hd] then b'[hd]); every lane of a half-wave reads the same address.
+// global re-read (a first version re-read q, k, v in the copy-out loop: +21 % / +28 % on the two kernels), and as packed-bf16
+// dot products (v_dot2c_f32_bf16: six VALU operations per four columns; the unpack / fma form cost +12 % / +26 %).  rsum / -b' of
+// the head's 3 hd columns sit in LDS as bf16 pairs (`vec`); every lane of a half-wave reads the same address (broadcast).
 // ------------------------------------------------------------------------------------------------
 template <int HD>
-__device__ __forceinline__ void store_rowfrag_dot(bf16_t* row, const f32x16_t (&acc)[HD / 32], int g, const float* vec, float& p1,
+__device__ __forceinline__ void store_rowfrag_dot(bf16_t* row, const f32x16_t (&acc)[HD / 32], int g, const uint4* vec, float& p1,
                                                   float& p2) {
 #pragma unroll
     for (int df = 0; df < HD / 32; ++df)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int d0 = df * 32 + 8 * q + 4 * g;
-            const uint2 o = *reinterpret_cast<const uint2*>(row + d0);
-            const float4 rs = *reinterpret_cast<const float4*>(vec + d0), bs = *reinterpret_cast<const float4*>(vec + HD + d0);
+            const uint2 o = *reinterpret_cast<const uint2*>(row + d0);      // the original q / k / v values about to be overwritten
+            const uint4 vv = vec[d0 >> 2];                                  // {rsum pair, rsum pair, -b' pair, -b' pair} of these 4 columns
             const uint32_t lo = pack_bf2(acc[df][4 * q], acc[df][4 * q + 1]), hi = pack_bf2(acc[df][4 * q + 2], acc[df][4 * q + 3]);
-            const float d0f = __uint_as_float(lo << 16), d1f = __uint_as_float(lo & 0xffff0000u);
-            const float d2f = __uint_as_float(hi << 16), d3f = __uint_as_float(hi & 0xffff0000u);
-            const float y0 = __uint_as_float(o.x << 16), y1 = __uint_as_float(o.x & 0xffff0000u);
-            const float y2 = __uint_as_float(o.y << 16), y3 = __uint_as_float(o.y & 0xffff0000u);
-            p1 = fmaf(d0f, rs.x, fmaf(d1f, rs.y, fmaf(d2f, rs.z, fmaf(d3f, rs.w, p1))));
-            p2 = fmaf(d0f, y0 - bs.x, fmaf(d1f, y1 - bs.y, fmaf(d2f, y2 - bs.z, fmaf(d3f, y3 - bs.w, p2))));
+            p1 = dot2_bf16(lo, vv.x, dot2_bf16(hi, vv.y, p1));
+            p2 = dot2_bf16(lo, o.x, dot2_bf16(hi, o.y, dot2_bf16(lo, vv.z, dot2_bf16(hi, vv.w, p2))));
             *reinterpret_cast<uint2*>(row + d0) = make_uint2(lo, hi);
         }
 }
-// vec[j][0 .. HD) = rsum[j C + h HD + d], vec[j][HD .. 2 HD) = bias_f[j C + h HD + d], j = q, k, v
+// vec[j * HD / 4 + d / 4] = bf16 pairs {rsum[d], rsum[d+1]}, {rsum[d+2], rsum[d+3]}, {-b'[d], -b'[d+1]}, {-b'[d+2], -b'[d+3]} of the
+// head's columns in tensor j = q, k, v (global column j C + h HD + d).  Rounding the two vectors to bf16 moves c1 / c2 by
+// ~1e-3 / sqrt(C) of a gradient element (independent errors over the 3 hd columns): far below the bf16 noise of the data.
 template <int HD>
-__device__ __forceinline__ void fill_stat_vec(float* vec, const float* __restrict__ rsum, const float* __restrict__ bias, int C, int h,
+__device__ __forceinline__ void fill_stat_vec(uint4* vec, const float* __restrict__ rsum, const float* __restrict__ bias, int C, int h,
                                               int gtid, int gsize) {
-    for (int idx = gtid; idx < 6 * HD; idx += gsize) {
-        const int j = idx / (2 * HD), rem = idx % (2 * HD), d = rem % HD;
-        vec[idx] = (rem < HD ? rsum : bias)[j * C + h * HD + d];
+    for (int idx = gtid; idx < 3 * HD / 4; idx += gsize) {
+        const int j = idx / (HD / 4), d = (idx % (HD / 4)) * 4;
+        const float4 r = *reinterpret_cast<const float4*>(rsum + j * C + h * HD + d);
+        const float4 b = *reinterpret_cast<const float4*>(bias + j * C + h * HD + d);
+        vec[idx] = make_uint4(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w), pack_bf2(-b.x, -b.y), pack_bf2(-b.z, -b.w));
     }
 }
 
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
     char* dot_ = vt + TILE;
     float* lse_s = reinterpret_cast<float*>(dot_ + TILE);
     float* del_s = lse_s + KP;
-    float* vec = del_s + KP;
+    uint4* vec = reinterpret_cast<uint4*>(del_s + KP);
     const bool stats = sizeof(T) == 2 && st_part != nullptr;      // wave-uniform
     const size_t rstride = (size_t)P.tstep * C3, ostride = (size_t)P.tstep * C;
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
@@ -655,12 +656,15 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
                 // lane taking the two dots of its row fragment with the values it overwrites
                 float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
                 store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(qt + (size_t)i * RSTR), dq, g, vec, a1, a2);
-                store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(kt + (size_t)i * RSTR), dk, g, vec + 2 * HD, b1, b2);
-                store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(vt + (size_t)i * RSTR), dv, g, vec + 4 * HD, b1, b2);
+                store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(kt + (size_t)i * RSTR), dk, g, vec + HD / 4, b1, b2);
+                store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(vt + (size_t)i * RSTR), dv, g, vec + 2 * (HD / 4), b1, b2);
                 a1 = wave_halves<WaveAdd>(a1); a2 = wave_halves<WaveAdd>(a2);      // the two column halves of a row: lanes i, i + 32
                 b1 = wave_halves<WaveAdd>(b1); b2 = wave_halves<WaveAdd>(b2);
-                if (rvalid && g == 0)
-                    *reinterpret_cast<float4*>(st_part + (tok * H + P.h) * 4) = make_float4(a1, a2, b1, b2);
+                if (rvalid && g == 0) {     // part[2 h + role][token]: the joints of a frame are consecutive tokens
+                    const size_t Mtot = (size_t)(nprob / H) * P.L;
+                    *reinterpret_cast<float2*>(st_part + ((size_t)(2 * P.h) * Mtot + tok) * 2) = make_float2(a1, a2);
+                    *reinterpret_cast<float2*>(st_part + ((size_t)(2 * P.h + 1) * Mtot + tok) * 2) = make_float2(b1, b2);
+                }
             }
         }
         if (!stats) {
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
     char* dot_ = vt + TB;
     float* lse_s = reinterpret_cast<float*>(dot_ + TB);
     float* del_s = lse_s + KP;
-    float* vec = del_s + KP;                 // 6 HD floats behind the statistics (row-dot vectors, stats variant)
+    uint4* vec = reinterpret_cast<uint4*>(del_s + KP);     // behind the statistics: the row-dot vectors (stats variant; KP % 32 == 0 keeps it 16-byte aligned)
     const size_t rstride = (size_t)P.tstep * C3, ostride = (size_t)P.tstep * C;
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     const T* dobase = d_o + P.tok0 * C + (size_t)P.h * HD;
@@ -864,13 +868,15 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
             if (wave < 8) {
                 store_rowfrag_dot<HD>(qt_row(qt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), g2, vec, p1, p2);
             } else {
-                store_rowfrag_dot<HD>(qt_row(kt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), g2, vec + 2 * HD, p1, p2);
-                store_rowfrag_dot<HD>(qt_row(vt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[HD / 32]), g2, vec + 4 * HD, p1, p2);
+                store_rowfrag_dot<HD>(qt_row(kt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), g2, vec + HD / 4, p1, p2);
+                store_rowfrag_dot<HD>(qt_row(vt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[HD / 32]), g2, vec + 2 * (HD / 4), p1, p2);
             }
             p1 = wave_halves<WaveAdd>(p1);
             p2 = wave_halves<WaveAdd>(p2);
-            if (g2 == 0 && row2 < P.L)
-                *reinterpret_cast<float2*>(st_part + ((P.tok0 + (size_t)row2 * P.tstep) * H + P.h) * 4 + (wave < 8 ? 0 : 2)) = make_float2(p1, p2);
+            if (g2 == 0 && row2 < P.L) {
+                const size_t Mtot = (size_t)(nprob / H) * P.L;
+                *reinterpret_cast<float2*>(st_part + ((size_t)(2 * P.h + (wave < 8 ? 0 : 1)) * Mtot + P.tok0 + (size_t)row2 * P.tstep) * 2) = make_float2(p1, p2);
+            }
         } else if (wave < 8) {
             store_rowfrag<T, HD>(reinterpret_cast<T*>(qt + (size_t)row2 * RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), 1.0f, g2);
         } else {
@@ -1033,11 +1039,11 @@ extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, con
                             int H, int hd, float scale, int mode, int dtype, void* stream) {
     return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, dtype, stream, nullptr, nullptr, nullptr);
 }
-// mbx_attn_bwd (bf16) + part[M][2H][2] = { sum dqkv rsum, sum dqkv (qkv - bias_f) } per (token, head, q | k+v columns); rsum, bias_f [3C] f32
+// mbx_attn_bwd (bf16) + part[2H][M][2] = { sum dqkv rsum, sum dqkv (qkv - bias_f) } per (head, q | k+v columns, token); rsum, bias_f [3C] f32
 extern "C" int mbx_attn_bwd_stats(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, const float* bias_f,
                                   const float* rsum, float* part, int B, int T, int J, int H, int hd, float scale, int mode,
                                   void* stream) {
     MBX_CHECK_ARG(bias_f && rsum && part, "attn_bwd_stats: null pointer");
-    MBX_CHECK_ARG((reinterpret_cast<uintptr_t>(part) & 15) == 0, "attn_bwd_stats: part must be 16-byte aligned");
+    MBX_CHECK_ARG((reinterpret_cast<uintptr_t>(part) & 7) == 0, "attn_bwd_stats: part must be 8-byte aligned");
     return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, MBX_BF16, stream, bias_f, rsum, part);
 }

@@ -791,27 +791,27 @@ extern "C" int mbx_fold_norm_weights(const int64_t* desc, int n_desc, int max_n,
     return 0;
 }
 
-// rowc[m] = {rstd, rstd c1, rstd c2, 0} from the producer's partial row dots part[m][nb][2] = {sum dY s, sum dY (Y - b')}
-// over nb column blocks (heads for the attention backward, 64-column blocks for the GELU' epilogue); fixed summation order.
+// rowc[m] = {rstd, rstd c1, rstd c2, 0} from the producers' partial row dots part[nb][M][2] = {sum dY s, sum dY (Y - b')} over
+// nb column blocks (2 x heads for the attention backward, 64-column blocks for the GELU' epilogue); block-major, so that both the
+// producers' stores and these loads run along the tokens; fixed summation order.
 __global__ __launch_bounds__(256) void lnbwd_rowc_kernel(const float* __restrict__ part, int nb, const float* __restrict__ rstd,
                                                          float4* __restrict__ rowc, int M, float invC) {
-    // (8 / nb2) rows per 8-lane group would complicate the indexing for little: one row per FOUR lanes, float2 per lane per step
-    const int m = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
-    float p1 = 0.f, p2 = 0.f;
-    if (m < M) {
-        const float2* pr = reinterpret_cast<const float2*>(part) + (size_t)m * nb;
-        for (int b = sub; b < nb; b += 4) { const float2 v = pr[b]; p1 += v.x; p2 += v.y; }
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float2* pr = reinterpret_cast<const float2*>(part) + m;
+    float p1 = 0.f, p2 = 0.f, q1 = 0.f, q2 = 0.f;
+    int b = 0;
+    for (; b + 1 < nb; b += 2) {
+        const float2 v0 = pr[(size_t)b * M], v1 = pr[(size_t)(b + 1) * M];
+        p1 += v0.x; p2 += v0.y; q1 += v1.x; q2 += v1.y;
     }
-    p1 += dpp_mov<0xB1>(p1, p1); p2 += dpp_mov<0xB1>(p2, p2);    // quad_perm [1,0,3,2]
-    p1 += dpp_mov<0x4E>(p1, p1); p2 += dpp_mov<0x4E>(p2, p2);    // quad_perm [2,3,0,1]
-    if (m < M && sub == 0) {
-        const float rs = rstd[m];
-        rowc[m] = make_float4(rs, rs * p1 * invC, rs * p2 * invC, 0.f);
-    }
+    if (b < nb) { const float2 v0 = pr[(size_t)b * M]; p1 += v0.x; p2 += v0.y; }
+    const float rs = rstd[m];
+    rowc[m] = make_float4(rs, rs * (p1 + q1) * invC, rs * (p2 + q2) * invC, 0.f);
 }
 extern "C" int mbx_lnbwd_rowc(const float* part, int nb, const float* rstd, float* rowc, int M, int C, void* stream) {
     MBX_CHECK_ARG(part && rstd && rowc && nb > 0 && M > 0 && C > 0, "lnbwd_rowc: bad arguments");
-    hipLaunchKernelGGL(lnbwd_rowc_kernel, dim3((M + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, nb, rstd,
+    hipLaunchKernelGGL(lnbwd_rowc_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nb, rstd,
                        reinterpret_cast<float4*>(rowc), M, 1.0f / (float)C);
     MBX_LAUNCH_CHECK("lnbwd_rowc");
     return 0;

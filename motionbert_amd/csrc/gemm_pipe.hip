@@ -177,6 +177,47 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
     if (dbg & 4) return;
     __builtin_amdgcn_s_barrier();                           // all waves are done reading the last stage
     char* er = smem + wave * (64 * EROW);                   // 9 KiB per wave, 72 KiB per workgroup
+#ifndef MBX_RESID_WIDE
+#define MBX_RESID_WIDE 0
+#endif
+    if constexpr (EPI == MBX_EPI_RESID && MBX_RESID_WIDE) {
+        // A/B variant of the residual epilogue on the 32 x 64 staging of the LayerNorm-backward epilogue below: eight lanes per row,
+        // eight columns per lane -> one instruction = 8 rows x 256 contiguous bytes (the default walk: 8 rows x 128 bytes)
+        constexpr int EP = 64 * 4 + 16;
+        const int rr8 = lane >> 3, cc = (lane & 7) * 8;
+        const int n = n0 + wn * 64 + cc, nc = min(n, N - 8);
+        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) { load4<float>(bias + nc, *reinterpret_cast<float (*)[4]>(&bb[0])); load4<float>(bias + nc + 4, *reinterpret_cast<float (*)[4]>(&bb[4])); }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int mb = m0 + wm * 64 + tm * 32;
+            float4 r0[4], r1[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const size_t mo = (size_t)min(mb + p * 8 + rr8, M - 1);
+                r0[p] = *reinterpret_cast<const float4*>(resid + mo * N + nc);
+                r1[p] = *reinterpret_cast<const float4*>(resid + mo * N + nc + 4);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(er + i * EP + (tn * 32 + 8 * q + 4 * g) * 4) =
+                        make_float4(acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int rl = p * 8 + rr8, m = mb + rl;
+                const float4 a0 = *reinterpret_cast<const float4*>(er + rl * EP + cc * 4);
+                const float4 a1 = *reinterpret_cast<const float4*>(er + rl * EP + cc * 4 + 16);
+                if (m < M && n < N) {
+                    const size_t o = (size_t)m * N + n;
+                    *reinterpret_cast<float4*>(out_f + o) = make_float4(a0.x + bb[0] + r0[p].x, a0.y + bb[1] + r0[p].y, a0.z + bb[2] + r0[p].z, a0.w + bb[3] + r0[p].w);
+                    *reinterpret_cast<float4*>(out_f + o + 4) = make_float4(a1.x + bb[4] + r1[p].x, a1.y + bb[5] + r1[p].y, a1.z + bb[6] + r1[p].z, a1.w + bb[7] + r1[p].w);
+                }
+            }
+        }
+        return;
+    }
     if constexpr (EPI == MBX_EPI_LNBWD) {
         // LayerNorm backward as the epilogue of the dX GEMM ("LayerNorm folding", elementwise.hip): acc = d(xhat),
         //   dx = dres [+ extra] + rstd acc - rstd c1 - xhat rstd c2,   rowc[m] = {rstd, rstd c1, rstd c2, -}.
@@ -454,8 +495,9 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
 // GELU' epilogue (second input stream `aux`): fp32 staging as in nt_epilogue, but each lane owns 8 columns: 16-byte
 // aux load, 16-byte store, one instruction = 8 rows x 128 B.
 // Round 3: with `st_part` the epilogue also leaves, per row and 64-column block, the two row dots the folded LayerNorm backward
-// needs (see "LayerNorm folding" in elementwise.hip): part[m][n / 64] = { sum_n du s[n], sum_n du (u - b'[n]) } over the
-// block's columns, du = the bf16-ROUNDED output (what the dX GEMM will read).  Eight lanes share a row: three DPP steps.
+// needs (see "LayerNorm folding" in elementwise.hip): part[n / 64][m] = { sum_n du s[n], sum_n du (u - b'[n]) } over the
+// block's columns, du = the bf16-ROUNDED output (what the dX GEMM will read), s and b' rounded to bf16 (packed-bf16 dot
+// products; see fill_stat_vec in attention.hip for the error budget).  Eight lanes share a row: three DPP steps.
 template <int NTN>
 __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char* er, bf16_t* __restrict__ out_t,
                                                   const bf16_t* __restrict__ aux, int M, int N, int row_base, int col_base,
@@ -467,12 +509,12 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
 #pragma unroll
     for (int h = 0; h < NTN / 2; ++h) {
         const int n = col_base + h * 64 + cc;
-        float sv[8], bv[8];
+        uint32_t svp[4] = {0u, 0u, 0u, 0u}, nbp[4] = {0u, 0u, 0u, 0u};   // bf16 pairs of rsum and of -b' for the lane's eight columns
         if (st_part) {
-            load4<float>(st_rsum + min(n, N - 8), *reinterpret_cast<float (*)[4]>(&sv[0]));
-            load4<float>(st_rsum + min(n, N - 8) + 4, *reinterpret_cast<float (*)[4]>(&sv[4]));
-            load4<float>(st_bias + min(n, N - 8), *reinterpret_cast<float (*)[4]>(&bv[0]));
-            load4<float>(st_bias + min(n, N - 8) + 4, *reinterpret_cast<float (*)[4]>(&bv[4]));
+            const float4 s0 = *reinterpret_cast<const float4*>(st_rsum + min(n, N - 8)), s1 = *reinterpret_cast<const float4*>(st_rsum + min(n, N - 8) + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(st_bias + min(n, N - 8)), b1 = *reinterpret_cast<const float4*>(st_bias + min(n, N - 8) + 4);
+            svp[0] = pack_bf2(s0.x, s0.y); svp[1] = pack_bf2(s0.z, s0.w); svp[2] = pack_bf2(s1.x, s1.y); svp[3] = pack_bf2(s1.z, s1.w);
+            nbp[0] = pack_bf2(-b0.x, -b0.y); nbp[1] = pack_bf2(-b0.z, -b0.w); nbp[2] = pack_bf2(-b1.x, -b1.y); nbp[3] = pack_bf2(-b1.z, -b1.w);
         }
         // the aux (pre-activation) stream runs one 32-row block ahead of the staging: its HBM latency is paid under the LDS
         // round trip of the previous block (clamped addresses, unconditional: out-of-range lanes never store)
@@ -510,10 +552,9 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
                     for (int e = 0; e < 4; ++e) {
                         const float u0 = __uint_as_float(uw[e] << 16), u1 = __uint_as_float(uw[e] & 0xffff0000u);
                         r[e] = pack_bf2(v[2 * e] * gelu_fast_grad(u0), v[2 * e + 1] * gelu_fast_grad(u1));
-                        if (st_part) {
-                            const float d0 = __uint_as_float(r[e] << 16), d1 = __uint_as_float(r[e] & 0xffff0000u);
-                            q1 = fmaf(d0, sv[2 * e], fmaf(d1, sv[2 * e + 1], q1));
-                            q2 = fmaf(d0, u0 - bv[2 * e], fmaf(d1, u1 - bv[2 * e + 1], q2));
+                        if (st_part) {      // packed-bf16 dots (v_dot2c_f32_bf16): du . rsum and du . (u - b')
+                            q1 = dot2_bf16(r[e], svp[e], q1);
+                            q2 = dot2_bf16(r[e], uw[e], dot2_bf16(r[e], nbp[e], q2));
                         }
                     }
                     *reinterpret_cast<uint4*>(out_t + o) = make_uint4(r[0], r[1], r[2], r[3]);
@@ -523,7 +564,7 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
                     q1 += dpp_mov<0x4E>(q1, q1); q2 += dpp_mov<0x4E>(q2, q2);      // quad_perm [2,3,0,1]
                     q1 += dpp_mov<0x141>(q1, q1); q2 += dpp_mov<0x141>(q2, q2);    // row_half_mirror: the other quad of the 8-lane group
                     if (ok && (lane & 7) == 0)
-                        *reinterpret_cast<float2*>(st_part + ((size_t)m * (N >> 6) + (n >> 6)) * 2) = make_float2(q1, q2);
+                        *reinterpret_cast<float2*>(st_part + ((size_t)(n >> 6) * M + m) * 2) = make_float2(q1, q2);   // [block][row]: 8 rows = 64 contiguous bytes
                 }
             }
         }
@@ -921,7 +962,7 @@ int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int
 }
 
 // ---- round 3: the two GEMM entries of the folded LayerNorm backward (see "LayerNorm folding" in elementwise.hip) --------------
-// du = (dy . W2) * gelu'(u)  (the DGELU epilogue) + the row dots part[M][N/64][2] of du with rsum and (u - bias_f)
+// du = (dy . W2) * gelu'(u)  (the DGELU epilogue) + the row dots part[N/64][M][2] of du with rsum and (u - bias_f)
 extern "C" int mbx_gemm_nt_dgelu_stats(const void* a, const void* w, void* out_t, const void* aux_t, const float* bias_f,
                                        const float* rsum, float* part, int M, int N, int K, void* stream) {
     MBX_CHECK_ARG(a && w && out_t && aux_t && bias_f && rsum && part, "gemm_nt_dgelu_stats: null pointer");

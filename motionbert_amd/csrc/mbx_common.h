@@ -47,6 +47,10 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, mbx_bf16x2_t));
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+// c + a.lo * b.lo + a.hi * b.hi on two packed bf16 pairs (v_dot2c_f32_bf16): row dots over bf16 data without unpacking
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(mbx_bf16x2_t, a), __builtin_bit_cast(mbx_bf16x2_t, b), c, false);
+}
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {

@@ -539,7 +539,7 @@ class Engine:
         dqkv = self._t(M, 3 * C)
         if self.fold:
             lin = f'{pre}.{attn}.qkv'
-            part = self._f(M, 2 * cfg.H, 2)       # per head: the q columns, the k + v columns
+            part = self._f(2 * cfg.H, M, 2)       # block-major; per head: the q columns, the k + v columns
             ops.attn_bwd_stats(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.Bf[lin], self.Rs[lin], part, self.B, self.Tlen, cfg.J, cfg.H,
                                cfg.scale, mode)
             del do
@@ -619,7 +619,7 @@ class Engine:
         del g
         if self.fold:
             lin = f'{pre}.{mlp}.fc1'
-            part = self._f(M, cfg.hidden // 64, 2)
+            part = self._f(cfg.hidden // 64, M, 2)
             ops.gemm_nt_dgelu_stats(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], du, sv['u'], self.Bf[lin], self.Rs[lin], part)
             return self._fold_tail(du, part, sv, lin, f'{pre}.{norm}', dy, extra, need_t)
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], None, EPI_DGELU, out_t=du, aux_t=sv['u'])

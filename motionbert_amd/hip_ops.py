@@ -238,7 +238,7 @@ class HipOps:
                                              float(scale), int(mode), self._stream()))
 
     def lnbwd_rowc(self, part, rstd, rowc, C):
-        M, nb = part.shape[0], part.shape[1]
+        nb, M = part.shape[0], part.shape[1]          # block-major partial row dots [nb, M, 2]
         self._ck(self.lib.mbx_lnbwd_rowc(_p(part), nb, _p(rstd), _p(rowc), M, int(C), self._stream()))
 
     def gemm_nt_lnbwd(self, a_t, w_t, xhat, rowc, dres, extra, dx, dx_t):

@@ -68,33 +68,40 @@ class MockOps:
             Rs[lin] = Wf.float().sum(1)
         return Wn, Wt, Bf, Rs
 
+    @staticmethod
+    def _stat_vec(v, dtype):
+        """The bf16 kernels take their row dots as packed-bf16 products: rsum and b' enter rounded to bf16 there."""
+        return v.to(torch.bfloat16).float() if dtype == torch.bfloat16 else v
+
     def gemm_nt_dgelu_stats(self, a_t, w_t, out_t, aux_t, bias_f, rsum, part):
-        """EPI_DGELU + part[m][n // 64] = { sum du rsum, sum du (u - bias_f) } over each 64-column block of the ROUNDED du."""
+        """EPI_DGELU + part[n // 64][m] = { sum du rsum, sum du (u - bias_f) } over each 64-column block of the ROUNDED du."""
         self._log(f'gemm_nt.{EPI_DGELU}.stats')
         acc = a_t.float() @ w_t.float().t()
         u = aux_t.float()
         out_t.copy_((acc * _gelu_grad(u)).to(out_t.dtype))
         d = out_t.float()
         M, N = d.shape
-        part.copy_(torch.stack([(d * rsum).reshape(M, N // 64, 64).sum(-1), (d * (u - bias_f)).reshape(M, N // 64, 64).sum(-1)], -1))
+        rsum, bias_f = self._stat_vec(rsum, out_t.dtype), self._stat_vec(bias_f, out_t.dtype)
+        part.copy_(torch.stack([(d * rsum).reshape(M, N // 64, 64).sum(-1), (d * (u - bias_f)).reshape(M, N // 64, 64).sum(-1)], -1).transpose(0, 1))
 
     def attn_bwd_stats(self, qkv, o, do, lse, dqkv, bias_f, rsum, part, B, T, J, H, scale, mode):
-        """attn_bwd + part[m][2 h + role] = { sum d rsum, sum d (qkv - bias_f) } of the rounded dqkv over the head's q columns
+        """attn_bwd + part[2 h + role][m] = { sum d rsum, sum d (qkv - bias_f) } of the rounded dqkv over the head's q columns
         (role 0) and over its k and v columns (role 1)."""
         self.attn_bwd(qkv, o, do, lse, dqkv, B, T, J, H, scale, mode)
         self.calls[-1] += '.stats'
         M = dqkv.shape[0]
+        rsum, bias_f = self._stat_vec(rsum, dqkv.dtype), self._stat_vec(bias_f, dqkv.dtype)
         d = dqkv.float().reshape(M, 3, H, -1)
         y = (qkv.float() - bias_f).reshape(M, 3, H, -1)
         t1, t2 = (d * rsum.reshape(1, 3, H, -1)).sum(3), (d * y).sum(3)            # [M, 3, H]
         p1 = torch.stack([t1[:, 0], t1[:, 1] + t1[:, 2]], -1)                       # [M, H, role]
         p2 = torch.stack([t2[:, 0], t2[:, 1] + t2[:, 2]], -1)
-        part.copy_(torch.stack([p1, p2], -1).reshape(part.shape))
+        part.copy_(torch.stack([p1, p2], -1).reshape(M, 2 * H, 2).transpose(0, 1))      # block-major [2H, M, 2]
 
     def lnbwd_rowc(self, part, rstd, rowc, C):
         """rowc[m] = {rstd, rstd c1, rstd c2, 0}, c = column-block sums of part / C."""
         self._log('lnbwd_rowc')
-        c = part.sum(1) / C
+        c = part.sum(0) / C        # part is block-major [nb, M, 2]
         rowc.copy_(torch.stack([rstd, rstd * c[:, 0], rstd * c[:, 1], torch.zeros_like(rstd)], -1))
 
     def gemm_nt_lnbwd(self, a_t, w_t, xhat, rowc, dres, extra, dx, dx_t):

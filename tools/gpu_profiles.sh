@@ -15,7 +15,7 @@ cd $GRAFT_REPO_ROOT
 { echo "# command: MBX_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -- $CMD"; python tools/rocpd_stats.py $DB 40; } > gpurun_out/${TAG}_kernel_stats.txt
 tail -1 gpurun_out/${TAG}_prof.log | cut -c1-300
 PCMD="python bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline"
-run() { tag=$1; shift; rm -rf /tmp/pmcb; timeout 400 rocprofv3 --pmc "$@" -d /tmp/pmcb -o p -- $PCMD > /dev/null 2>&1; python tools/pmc_stats.py $(find /tmp/pmcb -name "*.db" | head -1) "" | grep -E "gemm|attn|ln_|fuse|adamw|pose|embed|head|colsum|prep" > gpurun_out/pmc_bench_$tag.txt; echo "pmc $tag: $(wc -l < gpurun_out/pmc_bench_$tag.txt) rows"; }
+run() { tag=$1; shift; rm -rf /tmp/pmcb; timeout 400 rocprofv3 --pmc "$@" -d /tmp/pmcb -o p -- $PCMD > /dev/null 2>&1; python tools/pmc_stats.py $(find /tmp/pmcb -name "*.db" | head -1) "" | grep -E "gemm|attn|ln_|fuse|adamw|pose|embed|head|colsum|prep|fold|rowc" > gpurun_out/pmc_bench_$tag.txt; echo "pmc $tag: $(wc -l < gpurun_out/pmc_bench_$tag.txt) rows"; }
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run fetch FETCH_SIZE TCC_HIT_sum
 run write WRITE_SIZE TCC_MISS_sum
