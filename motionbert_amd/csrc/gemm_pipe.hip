@@ -177,47 +177,6 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
     if (dbg & 4) return;
     __builtin_amdgcn_s_barrier();                           // all waves are done reading the last stage
     char* er = smem + wave * (64 * EROW);                   // 9 KiB per wave, 72 KiB per workgroup
-#ifndef MBX_RESID_WIDE
-#define MBX_RESID_WIDE 0
-#endif
-    if constexpr (EPI == MBX_EPI_RESID && MBX_RESID_WIDE) {
-        // A/B variant of the residual epilogue on the 32 x 64 staging of the LayerNorm-backward epilogue below: eight lanes per row,
-        // eight columns per lane -> one instruction = 8 rows x 256 contiguous bytes (the default walk: 8 rows x 128 bytes)
-        constexpr int EP = 64 * 4 + 16;
-        const int rr8 = lane >> 3, cc = (lane & 7) * 8;
-        const int n = n0 + wn * 64 + cc, nc = min(n, N - 8);
-        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (bias) { load4<float>(bias + nc, *reinterpret_cast<float (*)[4]>(&bb[0])); load4<float>(bias + nc + 4, *reinterpret_cast<float (*)[4]>(&bb[4])); }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int mb = m0 + wm * 64 + tm * 32;
-            float4 r0[4], r1[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const size_t mo = (size_t)min(mb + p * 8 + rr8, M - 1);
-                r0[p] = *reinterpret_cast<const float4*>(resid + mo * N + nc);
-                r1[p] = *reinterpret_cast<const float4*>(resid + mo * N + nc + 4);
-            }
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(er + i * EP + (tn * 32 + 8 * q + 4 * g) * 4) =
-                        make_float4(acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int rl = p * 8 + rr8, m = mb + rl;
-                const float4 a0 = *reinterpret_cast<const float4*>(er + rl * EP + cc * 4);
-                const float4 a1 = *reinterpret_cast<const float4*>(er + rl * EP + cc * 4 + 16);
-                if (m < M && n < N) {
-                    const size_t o = (size_t)m * N + n;
-                    *reinterpret_cast<float4*>(out_f + o) = make_float4(a0.x + bb[0] + r0[p].x, a0.y + bb[1] + r0[p].y, a0.z + bb[2] + r0[p].z, a0.w + bb[3] + r0[p].w);
-                    *reinterpret_cast<float4*>(out_f + o + 4) = make_float4(a1.x + bb[4] + r1[p].x, a1.y + bb[5] + r1[p].y, a1.z + bb[6] + r1[p].z, a1.w + bb[7] + r1[p].w);
-                }
-            }
-        }
-        return;
-    }
     if constexpr (EPI == MBX_EPI_LNBWD) {
         // LayerNorm backward as the epilogue of the dX GEMM ("LayerNorm folding", elementwise.hip): acc = d(xhat),
         //   dx = dres [+ extra] + rstd acc - rstd c1 - xhat rstd c2,   rowc[m] = {rstd, rstd c1, rstd c2, -}.
