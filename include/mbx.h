@@ -143,9 +143,19 @@ int mbx_gemm_tn_x3(const void* dy_hi, const void* dy_lo, const void* a_hi, const
  * hd = C/H must be 32 or 64; J <= 32; T <= 256. */
 int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale,
                  int mode, int dtype, void* stream);
+/* mbx_attn_fwd with nn.Dropout(p) on the probabilities (attn_drop, DSTformer.py:96,182,196): o = (mask P / (1 - p)) V with the
+ * softmax statistics (and lse) of the undropped probabilities.  The mask is counter-based: element (query i, key j) of a
+ * problem survives iff keep(flat index of that element in the reference's attn tensor -- [B T, H, J, J] spatial,
+ * [B, H, J, T, T] temporal --, p, seed), motionbert_amd/dropmask.py.  0 <= p < 1; p = 0 is mbx_attn_fwd. */
+int mbx_attn_fwd_drop(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale,
+                      int mode, int dtype, float p, uint64_t seed, void* stream);
 /* dqkv [M,3C] T from do [M,C] T; probabilities are recomputed from q, k and lse. */
 int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T,
                  int J, int H, int hd, float scale, int mode, int dtype, void* stream);
+/* backward of mbx_attn_fwd_drop (same p and seed; o is the dropped forward output): dP = mask (dO V^T) / (1 - p), dV from the
+ * dropped probabilities, dS = P (dP - rowsum(dO o)). */
+int mbx_attn_bwd_drop(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T,
+                      int J, int H, int hd, float scale, int mode, int dtype, float p, uint64_t seed, void* stream);
 /* mbx_attn_bwd (bf16) + part[2H][M][2] f32 = per (head, role, token) { sum dqkv rsum, sum dqkv (qkv - bias_f) } of the rounded
  * output over the head's q columns (role 0) and over its k and v columns (role 1) (LayerNorm folding, above; nb = 2H for
  * mbx_lnbwd_rowc; rsum, bias_f f32 [3C], entering rounded to bf16).  part must be 8-byte aligned. */

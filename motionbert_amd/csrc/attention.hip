@@ -206,6 +206,7 @@ __device__ __forceinline__ void store_rowfrag(T* row, const f32x16_t (&acc)[HD /
 
 struct Prob {
     size_t tok0;
+    size_t dbase;     // flat index of this problem's probability element (0, 0) in the reference's attn tensor (dropout masks)
     int tstep, L, h;
 };
 __device__ __forceinline__ Prob decode_prob(int prob, int mode, int Tn, int J, int H) {
@@ -214,11 +215,21 @@ __device__ __forceinline__ Prob decode_prob(int prob, int mode, int Tn, int J, i
     const int rest = prob / H;
     if (mode == MBX_ATTN_SPATIAL) {
         p.tok0 = (size_t)rest * J; p.tstep = 1; p.L = J;
+        p.dbase = ((size_t)rest * H + p.h) * J * J;                       // attn [B T, H, J, J]       (DSTformer.py:180)
     } else {
         const int j = rest % J, b = rest / J;
         p.tok0 = (size_t)b * Tn * J + j; p.tstep = J; p.L = Tn;
+        p.dbase = (((size_t)b * H + p.h) * J + j) * Tn * Tn;              // attn [B, H, J, T, T]      (DSTformer.py:194)
     }
     return p;
+}
+// Dropout on the attention probabilities (nn.Dropout(attn_drop), DSTformer.py:96,182,196): multiplier keep / (1 - p) of element
+// (query qi, key ki) -- the counter-based mask of dropmask.py over the flat index of the reference's attn tensor.  The softmax
+// statistics (row max, row sum, lse) are those of the UNdropped probabilities; in backward dP = mask (dO V^T) and
+// delta = rowsum(dO O) as without dropout (O already carries the mask).
+__device__ __forceinline__ float drop_mul(const MbxDrop& dr, size_t dbase, int qi, int ki, int L) {
+    const size_t idx = dbase + (size_t)qi * L + ki;
+    return drop_keep(dr.seed_lo, dr.seed_hi, (uint32_t)idx, (uint32_t)(idx >> 32), dr.thresh) ? dr.scale : 0.f;
 }
 
 template <typename T> __host__ __device__ constexpr int rm_stride(int HD) { return HD * AT<T>::SZ + 16; }   // row-major tile
@@ -227,9 +238,9 @@ template <typename T> __host__ __device__ constexpr int rm_stride(int HD) { retu
 // forward: flash-style walk over 32-key fragments with a running row max / row sum (the whole row
 // is at most 8 fragments, but keeping only one fragment of scores live keeps the wave at ~100 VGPRs)
 // ================================================================================================
-template <typename T, int HD, bool SHARED>
-__global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) == 2) ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
-                                                       int Tn, int J, int H, float scale, int mode, int nprob, int KP) {
+template <typename T, int HD, bool SHARED, bool DROP = false>
+__global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) == 2 && !DROP) ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+                                                       int Tn, int J, int H, float scale, int mode, int nprob, int KP, MbxDrop dr) {
     constexpr bool IS_BF = sizeof(T) == 2;
     constexpr int KSTR = rm_stride<T>(HD);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -297,6 +308,10 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) ==
             }
             l = fmaf(l, corr, ps);
             m2 = mn2;
+            if (DROP) {       // the row sum above is the undropped one; what multiplies V carries the mask
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] *= drop_mul(dr, P.dbase, q, 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g, P.L);
+            }
 #pragma unroll
             for (int df = 0; df < HD / 32; ++df) {
 #pragma unroll
@@ -327,11 +342,11 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) ==
 // ================================================================================================
 // backward, part 1: dQ   (lane = query)
 // ================================================================================================
-template <typename T, int HD, bool SHARED>
-__global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) == 2) ? 4 : 1) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+template <typename T, int HD, bool SHARED, bool DROP = false>
+__global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) == 2 && !DROP) ? 4 : 1) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                           const T* __restrict__ d_o, const float* __restrict__ lse,
                                                           T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
-                                                          int nprob, int KP) {
+                                                          int nprob, int KP, MbxDrop dr) {
     constexpr bool IS_BF = sizeof(T) == 2;
     constexpr int RSTR = rm_stride<T>(HD);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -380,7 +395,8 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) ==
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lq2));
-                s[r] = p * (dp[r] - delta) * scale;  // dS
+                const float dpr = DROP ? dp[r] * drop_mul(dr, P.dbase, q, 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g, P.L) : dp[r];
+                s[r] = p * (dpr - delta) * scale;  // dS
             }
 #pragma unroll
             for (int df = 0; df < HD / 32; ++df) MmaCols<T>::run(kt, RSTR, df * 32, f, s, lane, dq[df]);
@@ -392,11 +408,11 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) ==
 // ================================================================================================
 // backward, part 2: dK, dV   (lane = key)
 // ================================================================================================
-template <typename T, int HD, bool SHARED>
-__global__ __launch_bounds__(AttnBlockKV<SHARED>::THREADS, SHARED ? 2 : 1) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+template <typename T, int HD, bool SHARED, bool DROP = false>
+__global__ __launch_bounds__(AttnBlockKV<SHARED>::THREADS, (SHARED && !DROP) ? 2 : 1) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                            const T* __restrict__ d_o, const float* __restrict__ lse,
                                                            T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
-                                                           int nprob, int KP) {
+                                                           int nprob, int KP, MbxDrop dr) {
     constexpr bool IS_BF = sizeof(T) == 2;
     constexpr int RSTR = rm_stride<T>(HD);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -471,8 +487,9 @@ __global__ __launch_bounds__(AttnBlockKV<SHARED>::THREADS, SHARED ? 2 : 1) void 
                     const int r = 4 * qd + e;
                     // no masks: padded queries have zero Q and dO rows (dS^T Q = 0, P^T dO = 0), invalid key lanes are not stored
                     const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -la[e]));
-                    dp[r] = p * (dp[r] - da[e]) * scale;  // dS
-                    s[r] = p;                              // P
+                    const float km = DROP ? drop_mul(dr, P.dbase, q0 + e, key, P.L) : 1.f;
+                    dp[r] = p * (dp[r] * km - da[e]) * scale;  // dS
+                    s[r] = p * km;                             // P (dropped: what multiplied V in forward)
                 }
             }
 #pragma unroll
@@ -544,12 +561,12 @@ __device__ __forceinline__ void fill_stat_vec(uint4* vec, const float* __restric
 // serve both orientations (lane = query for dQ, lane = key for dK/dV), so qkv/dO/O are read from HBM once
 // and dqkv is written once: 2.2 GB per launch at 64 clips instead of 3.5 GB for the two-kernel form.
 // ================================================================================================
-template <typename T, int HD>
+template <typename T, int HD, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                              const T* __restrict__ d_o, const float* __restrict__ lse,
                                                              T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
                                                              int nprob, const float* __restrict__ st_bias,
-                                                             const float* __restrict__ st_rsum, float* __restrict__ st_part) {
+                                                             const float* __restrict__ st_rsum, float* __restrict__ st_part, MbxDrop dr) {
     constexpr int KP = 32;
     constexpr int RSTR = rm_stride<T>(HD);
     constexpr int TILE = KP * RSTR;
@@ -619,7 +636,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
         for (int r = 0; r < 16; ++r) {
             const int key = (r & 3) + 8 * (r >> 2) + 4 * g;
             const float pr = (rvalid && key < P.L) ? __expf(sf[r] * scale - lq) : 0.f;
-            sf[r] = pr * (dp[r] - delta) * scale;
+            const float dpr = DROP ? dp[r] * drop_mul(dr, P.dbase, min(i, P.L - 1), min(key, P.L - 1), P.L) : dp[r];
+            sf[r] = pr * (dpr - delta) * scale;
         }
 #pragma unroll
         for (int df = 0; df < HD / 32; ++df) MmaCols<T>::run(kt, RSTR, df * 32, 0, sf, lane, dq[df]);
@@ -651,8 +669,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * qd + e;
                 const float pr = (rvalid && q0 + e < P.L) ? __expf(sf[r] * scale - la[e]) : 0.f;
-                dp[r] = pr * (dp[r] - da[e]) * scale;
-                sf[r] = pr;
+                const float km = DROP ? drop_mul(dr, P.dbase, min(q0 + e, P.L - 1), min(i, P.L - 1), P.L) : 1.f;
+                dp[r] = pr * (dp[r] * km - da[e]) * scale;
+                sf[r] = pr * km;
             }
         }
 #pragma unroll
@@ -943,21 +962,32 @@ static int set_lds(K kernel, size_t bytes, const char* who) {
     return 0;
 }
 
-template <typename T, int HD, bool SHARED>
-static int launch_fwd(const void* qkv, void* o, float* lse, int Tn, int J, int H, float scale, int mode, int nprob, int KP, hipStream_t s) {
+// p in [0, 1): 0 = no dropout (the kernels without the mask code)
+static int make_drop(const char* who, float p, uint64_t seed, MbxDrop& dr) {
+    MBX_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout rate %g outside [0, 1)", who, (double)p);
+    dr.seed_lo = (uint32_t)seed;
+    dr.seed_hi = (uint32_t)(seed >> 32);
+    dr.thresh = p > 0.f ? (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f) : 0u;
+    dr.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return 0;
+}
+
+template <typename T, int HD, bool SHARED, bool DROP>
+static int launch_fwd(const void* qkv, void* o, float* lse, int Tn, int J, int H, float scale, int mode, int nprob, int KP, hipStream_t s,
+                      const MbxDrop& dr) {
     constexpr bool IS_BF = sizeof(T) == 2;
     const size_t per = (size_t)2 * KP * rm_stride<T>(HD);
     const size_t shm = SHARED ? per : 4 * per;
-    auto kern = attn_fwd_kernel<T, HD, SHARED>;
+    auto kern = attn_fwd_kernel<T, HD, SHARED, DROP>;
     if (set_lds(kern, shm, "attn_fwd")) return 1;
     const int grid = SHARED ? nprob : (nprob + 3) / 4;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(AttnBlock<SHARED>::THREADS), shm, s, (const T*)qkv, (T*)o, lse, Tn, J, H, scale, mode, nprob, KP);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(AttnBlock<SHARED>::THREADS), shm, s, (const T*)qkv, (T*)o, lse, Tn, J, H, scale, mode, nprob, KP, dr);
     MBX_LAUNCH_CHECK("attn_fwd");
     return 0;
 }
 
-extern "C" int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale, int mode,
-                            int dtype, void* stream) {
+static int attn_fwd_impl(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale, int mode,
+                         int dtype, void* stream, const MbxDrop& dr) {
     MBX_CHECK_ARG(qkv && o && lse, "attn_fwd: null pointer");
     MBX_CHECK_ARG(scale > 0.f, "attn_fwd: scale must be positive (the running max is taken over the raw scores), got %g", (double)scale);
     if (check_attn_args("attn_fwd", B, T, J, H, hd, mode, dtype)) return 1;
@@ -966,37 +996,54 @@ extern "C" int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, 
     const int KP = ((L + 31) / 32) * 32;
     const bool shared = KP > 32;
     hipStream_t s = (hipStream_t)stream;
-#define MBX_FWD(TT, HDV)                                                                         \
-    (shared ? launch_fwd<TT, HDV, true>(qkv, o, lse, T, J, H, scale, mode, nprob, KP, s)          \
-            : launch_fwd<TT, HDV, false>(qkv, o, lse, T, J, H, scale, mode, nprob, KP, s))
+#define MBX_FWD2(TT, HDV, DR)                                                                        \
+    (shared ? launch_fwd<TT, HDV, true, DR>(qkv, o, lse, T, J, H, scale, mode, nprob, KP, s, dr)       \
+            : launch_fwd<TT, HDV, false, DR>(qkv, o, lse, T, J, H, scale, mode, nprob, KP, s, dr))
+#define MBX_FWD(TT, HDV) (dr.thresh ? MBX_FWD2(TT, HDV, true) : MBX_FWD2(TT, HDV, false))
     if (dtype == MBX_BF16) return hd == 64 ? MBX_FWD(bf16_t, 64) : MBX_FWD(bf16_t, 32);
     return hd == 64 ? MBX_FWD(float, 64) : MBX_FWD(float, 32);
 #undef MBX_FWD
+#undef MBX_FWD2
+}
+extern "C" int mbx_attn_fwd(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale, int mode,
+                            int dtype, void* stream) {
+    MbxDrop dr;
+    make_drop("attn_fwd", 0.f, 0, dr);
+    return attn_fwd_impl(qkv, o, lse, B, T, J, H, hd, scale, mode, dtype, stream, dr);
+}
+// mbx_attn_fwd with nn.Dropout(p) on the probabilities (DSTformer.py:96,182,196): o = (mask P / (1 - p)) V, lse of the undropped
+// softmax; the mask is dropmask.keep(flat index in the reference's attn tensor, p, seed)
+extern "C" int mbx_attn_fwd_drop(const void* qkv, void* o, float* lse, int B, int T, int J, int H, int hd, float scale, int mode,
+                                 int dtype, float p, uint64_t seed, void* stream) {
+    MbxDrop dr;
+    if (make_drop("attn_fwd_drop", p, seed, dr)) return 1;
+    return attn_fwd_impl(qkv, o, lse, B, T, J, H, hd, scale, mode, dtype, stream, dr);
 }
 
-template <typename T, int HD, bool SHARED>
+template <typename T, int HD, bool SHARED, bool DROP>
 static int launch_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int Tn, int J, int H,
-                      float scale, int mode, int nprob, int KP, hipStream_t s) {
+                      float scale, int mode, int nprob, int KP, hipStream_t s, const MbxDrop& dr) {
     constexpr bool IS_BF = sizeof(T) == 2;
     const int RSTR = rm_stride<T>(HD);
     const size_t per_dq = (size_t)2 * KP * RSTR;
     const size_t per_dkv = (size_t)2 * KP * RSTR + 2 * KP * 4;
     const int grid = SHARED ? nprob : (nprob + 3) / 4;
-    auto k1 = attn_bwd_dq_kernel<T, HD, SHARED>;
-    auto k2 = attn_bwd_dkv_kernel<T, HD, SHARED>;
+    auto k1 = attn_bwd_dq_kernel<T, HD, SHARED, DROP>;
+    auto k2 = attn_bwd_dkv_kernel<T, HD, SHARED, DROP>;
     const size_t shm1 = SHARED ? per_dq : 4 * per_dq, shm2 = SHARED ? per_dkv : 4 * per_dkv;
     if (set_lds(k1, shm1, "attn_bwd_dq") || set_lds(k2, shm2, "attn_bwd_dkv")) return 1;
-    hipLaunchKernelGGL(k1, dim3(grid), dim3(AttnBlock<SHARED>::THREADS), shm1, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP);
+    hipLaunchKernelGGL(k1, dim3(grid), dim3(AttnBlock<SHARED>::THREADS), shm1, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP, dr);
     MBX_LAUNCH_CHECK("attn_bwd_dq");
-    hipLaunchKernelGGL(k2, dim3(grid), dim3(AttnBlockKV<SHARED>::THREADS), shm2, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP);
+    hipLaunchKernelGGL(k2, dim3(grid), dim3(AttnBlockKV<SHARED>::THREADS), shm2, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP, dr);
     MBX_LAUNCH_CHECK("attn_bwd_dkv");
     return 0;
 }
 
 static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
                          int H, int hd, float scale, int mode, int dtype, void* stream, const float* st_bias, const float* st_rsum,
-                         float* st_part) {
+                         float* st_part, const MbxDrop& dr) {
     MBX_CHECK_ARG(qkv && o && d_o && lse && dqkv, "attn_bwd: null pointer");
+    MBX_CHECK_ARG(!(st_part && dr.thresh), "attn_bwd: the row dots of the folded LayerNorm backward and dropout do not combine");
     if (check_attn_args("attn_bwd", B, T, J, H, hd, mode, dtype)) return 1;
     const int L = mode == MBX_ATTN_SPATIAL ? J : T;
     const int nprob = mode == MBX_ATTN_SPATIAL ? B * T * H : B * J * H;
@@ -1004,7 +1051,7 @@ static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
     const bool shared = KP > 32;
     hipStream_t s = (hipStream_t)stream;
 #ifndef MBX_ATTN_BWD_TWO_KERNELS      // A/B builds only (tools/build_variants.py): force the dQ + dK/dV kernel pair
-    if (shared && dtype == MBX_BF16) {
+    if (shared && dtype == MBX_BF16 && !dr.thresh) {   // dropout: the dQ + dK/dV pair below (this kernel sits at its 128-VGPR budget: the mask hash spills)
         const size_t shm = (size_t)4 * KP * rm_stride<bf16_t>(hd) + 2 * KP * 4 + 6 * hd * 4;
         if (shm <= 160 * 1024) {
 #define MBX_BWD_FUSED(HDV)                                                                                            \
@@ -1022,32 +1069,45 @@ static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
     }
 #endif
     if (!shared) {
-#define MBX_BWD_SMALL(TT, HDV)                                                                                        \
+#define MBX_BWD_SMALL2(TT, HDV, DR)                                                                                   \
     do {                                                                                                              \
         const size_t shm = (size_t)4 * (4 * 32 * rm_stride<TT>(HDV) + 2 * 32 * 4 + 6 * HDV * 4);                      \
-        auto k = attn_bwd_small_kernel<TT, HDV>;                                                                      \
+        auto k = attn_bwd_small_kernel<TT, HDV, DR>;                                                                  \
         if (set_lds(k, shm, "attn_bwd_small")) return 1;                                                              \
         hipLaunchKernelGGL(k, dim3((nprob + 3) / 4), dim3(256), shm, s, (const TT*)qkv, (const TT*)o, (const TT*)d_o, lse, \
-                           (TT*)dqkv, T, J, H, scale, mode, nprob, st_bias, st_rsum, st_part);                        \
+                           (TT*)dqkv, T, J, H, scale, mode, nprob, st_bias, st_rsum, st_part, dr);                    \
         MBX_LAUNCH_CHECK("attn_bwd_small");                                                                           \
         return 0;                                                                                                     \
     } while (0)
+#define MBX_BWD_SMALL(TT, HDV) do { if (dr.thresh) MBX_BWD_SMALL2(TT, HDV, true); else MBX_BWD_SMALL2(TT, HDV, false); } while (0)
         if (dtype == MBX_BF16) { if (hd == 64) MBX_BWD_SMALL(bf16_t, 64); else MBX_BWD_SMALL(bf16_t, 32); }
         else { if (hd == 64) MBX_BWD_SMALL(float, 64); else MBX_BWD_SMALL(float, 32); }
 #undef MBX_BWD_SMALL
+#undef MBX_BWD_SMALL2
     }
     MBX_CHECK_ARG(!st_part, "attn_bwd_stats: this shape runs the two-kernel backward, which has no row-dot output");
-#define MBX_BWD(TT, HDV)                                                                                             \
-    (shared ? launch_bwd<TT, HDV, true>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s)                   \
-            : launch_bwd<TT, HDV, false>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s))
+#define MBX_BWD2(TT, HDV, DR)                                                                                         \
+    (shared ? launch_bwd<TT, HDV, true, DR>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s, dr)           \
+            : launch_bwd<TT, HDV, false, DR>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s, dr))
+#define MBX_BWD(TT, HDV) (dr.thresh ? MBX_BWD2(TT, HDV, true) : MBX_BWD2(TT, HDV, false))
     if (dtype == MBX_BF16) return hd == 64 ? MBX_BWD(bf16_t, 64) : MBX_BWD(bf16_t, 32);
     return hd == 64 ? MBX_BWD(float, 64) : MBX_BWD(float, 32);
 #undef MBX_BWD
+#undef MBX_BWD2
 }
 
 extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
                             int H, int hd, float scale, int mode, int dtype, void* stream) {
-    return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, dtype, stream, nullptr, nullptr, nullptr);
+    MbxDrop dr;
+    make_drop("attn_bwd", 0.f, 0, dr);
+    return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, dtype, stream, nullptr, nullptr, nullptr, dr);
+}
+// backward of mbx_attn_fwd_drop (same p and seed): dP = mask (dO V^T) / (1 - p), dV from the dropped probabilities
+extern "C" int mbx_attn_bwd_drop(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
+                                 int H, int hd, float scale, int mode, int dtype, float p, uint64_t seed, void* stream) {
+    MbxDrop dr;
+    if (make_drop("attn_bwd_drop", p, seed, dr)) return 1;
+    return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, dtype, stream, nullptr, nullptr, nullptr, dr);
 }
 // mbx_attn_bwd (bf16) + part[2H][M][2] = { sum dqkv rsum, sum dqkv (qkv - bias_f) } per (head, q | k+v columns, token); rsum, bias_f [3C] f32
 extern "C" int mbx_attn_bwd_stats(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, const float* bias_f,
@@ -1055,5 +1115,7 @@ extern "C" int mbx_attn_bwd_stats(const void* qkv, const void* o, const void* d_
                                   void* stream) {
     MBX_CHECK_ARG(bias_f && rsum && part, "attn_bwd_stats: null pointer");
     MBX_CHECK_ARG((reinterpret_cast<uintptr_t>(part) & 7) == 0, "attn_bwd_stats: part must be 8-byte aligned");
-    return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, MBX_BF16, stream, bias_f, rsum, part);
+    MbxDrop dr;
+    make_drop("attn_bwd_stats", 0.f, 0, dr);
+    return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, MBX_BF16, stream, bias_f, rsum, part, dr);
 }

@@ -658,9 +658,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
                                                                const float* __restrict__ bias, typename std::conditional<X3, float, bf16_t>::type* __restrict__ out_t,
                                                                typename std::conditional<X3, float, bf16_t>::type* __restrict__ out2_t, float* __restrict__ out_f,
                                                                const float* __restrict__ resid, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ aux,
-                                                               int M, int N, int K, int ntn, long long* trace,
+                                                               int M, int N, int K, int ntn,
                                                                const float* __restrict__ st_bias, const float* __restrict__ st_rsum,
-                                                               float* __restrict__ st_part) {
+                                                               float* __restrict__ st_part
+#ifdef MBX_DIAG
+                                                               , long long* trace      // cycle stamps: diagnostic builds only
+#endif
+                                                               ) {
     typedef typename std::conditional<X3, float, bf16_t>::type TO;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 stages x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -830,9 +834,10 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
             break;                                                                                                    \
         }
     static long long* const pptrace = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
+#define MBX_Q_TRACE_ARG , pptrace
 #else
 #define MBX_Q_LOCKSTEP(E)
-    long long* const pptrace = nullptr;
+#define MBX_Q_TRACE_ARG
 #endif
 #define MBX_Q_CASE(E)                                                                                                 \
     case E:                                                                                                           \
@@ -840,8 +845,8 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
         if (set_lds_attr(gemm_nt_pp256_kernel<E>, shm, "gemm_nt_pp256")) return 1;                                    \
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w,        \
                            (const bf16_t*)nullptr, (const bf16_t*)nullptr, bias,                                      \
-                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn, pptrace, \
-                           st_bias, st_rsum, st_part);                                                                \
+                           (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn,          \
+                           st_bias, st_rsum, st_part MBX_Q_TRACE_ARG);                                                \
         break;
     switch (epi) {
         MBX_Q_CASE(MBX_EPI_STORE)
@@ -853,6 +858,7 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
     }
 #undef MBX_Q_CASE
 #undef MBX_Q_LOCKSTEP
+#undef MBX_Q_TRACE_ARG
     MBX_LAUNCH_CHECK("gemm_nt_pp256");
     return 0;
 }
@@ -864,12 +870,17 @@ int mbx_launch_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_hi, 
     const int ntn = (N + Q_BN - 1) / Q_BN, ntm = (M + Q_BM - 1) / Q_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
     const size_t shm = Q_NSTAGE * Q_STAGE;
+#ifdef MBX_DIAG
+#define MBX_X3_TRACE_ARG , (long long*)nullptr
+#else
+#define MBX_X3_TRACE_ARG
+#endif
 #define MBX_X3_CASE(E)                                                                                                \
     case E:                                                                                                           \
         if (set_lds_attr(gemm_nt_pp256_kernel<E, true>, shm, "gemm_nt_x3")) return 1;                                 \
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E, true>), grid, block, shm, s, (const bf16_t*)a_hi, (const bf16_t*)w_hi, \
                            (const bf16_t*)a_lo, (const bf16_t*)w_lo, bias, out_t, out2_t, out_f, resid, aux, M, N, K, ntn, \
-                           (long long*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);       \
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr MBX_X3_TRACE_ARG);           \
         break;
     switch (epi) {
         MBX_X3_CASE(MBX_EPI_STORE)

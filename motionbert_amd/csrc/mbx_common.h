@@ -119,6 +119,22 @@ template <typename Op> __device__ __forceinline__ float wave_halves(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return wave_reduce<WaveAdd>(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_reduce<WaveMax>(v); }
 
+// ---------------------------------------------------------------- counter-based dropout masks (restated in motionbert_amd/dropmask.py)
+// element index = 64 bit, passed as its two halves (the 4 elements a thread owns differ only in the low two bits)
+__device__ __forceinline__ bool drop_keep(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_lo, uint32_t idx_hi, uint32_t thresh) {
+    // two rounds of a 32-bit multiply-xorshift mix over (idx, seed); keep <=> the 32-bit hash >= p * 2^32
+    uint32_t h = idx_lo * 0x9E3779B1u ^ seed_lo;
+    h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+    h += idx_hi * 0xC2B2AE3Du + seed_hi;
+    h ^= h >> 16; h *= 0x27D4EB2Fu; h ^= h >> 15;
+    return h >= thresh;
+}
+// attention-probability dropout (nn.Dropout on the softmax output, DSTformer.py:96,182,196): thresh = 0 -> off
+struct MbxDrop {
+    uint32_t seed_lo, seed_hi, thresh;
+    float scale;      // 1 / (1 - p)
+};
+
 // ---------------------------------------------------------------- activation math (fp32)
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float u) {

@@ -202,15 +202,7 @@ extern "C" int mbx_adamw_step(float* p, const float* g, float* m, float* v, size
 // never materialised.  keep(idx) is a counter-based hash of (seed, element index): the same mask in both passes without
 // storing it.  p = 0 (evaluation, or dropout_ratio 0) skips the hash.
 // ---------------------------------------------------------------------------------------------------------------
-// element index = 64 bit, passed as its two halves (the 4 elements a thread owns differ only in the low two bits)
-__device__ __forceinline__ bool drop_keep(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_lo, uint32_t idx_hi, uint32_t thresh) {
-    // two rounds of a 32-bit multiply-xorshift mix over (idx, seed); keep <=> the 32-bit hash >= p * 2^32
-    uint32_t h = idx_lo * 0x9E3779B1u ^ seed_lo;
-    h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
-    h += idx_hi * 0xC2B2AE3Du + seed_hi;
-    h ^= h >> 16; h *= 0x27D4EB2Fu; h ^= h >> 15;
-    return h >= thresh;
-}
+// (drop_keep, the counter-based keep decision, lives in mbx_common.h: the attention kernels use it for the probability dropout)
 // one block per (n, j); thread c4 owns 4 consecutive channels; loops over (m, t)
 __global__ __launch_bounds__(128) void pool_rep_fwd_kernel(const float* __restrict__ rep, float* __restrict__ pooled, int Mp, int T,
                                                            int J, int R, float p, uint32_t seed_lo, uint32_t seed_hi) {

@@ -123,7 +123,7 @@ class Engine:
         # Dropout / DropPath: active only in training with a rate > 0 -- `drop_seed` is then the base seed of this
         # forward pass (None = everything off, the case of every shipped config).  Masks are counter-based (dropmask.py): the
         # element-wise ones and DropPath run as three small kernels around the fused path, the attention-probability dropout
-        # as a plain-torch fallback of the attention core (the fused kernels never materialise the probabilities).
+        # inside the attention kernels (round 3: the mask is a hash of the element's index in the reference's attn tensor).
         self.drop_seed = drop_seed
         # low-memory mode (model.recompute): what only feeds GEMMs in backward -- the LayerNorm output of every sub-layer and the
         # MLP's post-activation -- is rebuilt there (one LayerNorm-forward / one GELU launch each) instead of being kept: 14 -> 12
@@ -213,28 +213,6 @@ class Engine:
             return None
         ss = lambda kind: site_seed(self.drop_seed, level, stream, sub, kind)
         return (cfg.drop, ss(1), ss(2), pp, ss(3), cfg.attn_drop, ss(0))
-
-    def _torch_attention(self, qkv, mode, p, seed):
-        """Attention core with dropout on the probabilities, in plain torch (DSTformer.py:178-200 restated on the [M, 3C] qkv
-        layout); returns the T-typed output and the autograd tape for `_torch_attention_bwd`."""
-        from .dropmask import mask_like
-        cfg = self.cfg
-        B, T, J, H, hd = self.B, self.Tlen, cfg.J, cfg.H, cfg.hd
-        with torch.enable_grad():
-            leaf = qkv.detach().float().requires_grad_(True)
-            q5 = leaf.reshape(B * T, J, 3, H, hd).permute(2, 0, 3, 1, 4)          # [3, BF, H, J, hd]
-            q, k, v = q5[0], q5[1], q5[2]
-            if mode == MODE_SPATIAL:
-                attn = ((q @ k.transpose(-2, -1)) * cfg.scale).softmax(dim=-1)     # [BF, H, J, J]
-                attn = attn * mask_like(attn.detach(), p, seed)
-                o = (attn @ v).transpose(1, 2).reshape(B * T * J, H * hd)
-            else:
-                tt = lambda z: z.reshape(B, T, H, J, hd).permute(0, 2, 3, 1, 4)   # [B, H, J, T, hd]
-                qt, kt, vt = tt(q), tt(k), tt(v)
-                attn = ((qt @ kt.transpose(-2, -1)) * cfg.scale).softmax(dim=-1)   # [B, H, J, T, T]
-                attn = attn * mask_like(attn.detach(), p, seed)
-                o = (attn @ vt).permute(0, 3, 2, 1, 4).reshape(B * T * J, H * hd)
-        return o.detach().to(self.T), (leaf, o)
 
     def _xn(self, sv, pre, norm):
         """The normalised GEMM operand of a sub-layer in backward: the saved one, or (recompute mode) LayerNorm of the saved input."""
@@ -386,21 +364,20 @@ class Engine:
         qkv = self._t(M, 3 * C)
         ops.gemm_nt(xn, self.Wn[f'{pre}.{attn}.qkv'], self.Bf[f'{pre}.{attn}.qkv'] if self.fold else self._bias(f'{pre}.{attn}.qkv'),
                     EPI_STORE, out_t=qkv)
-        dm, tape = self._drops(pre, sub), None
-        if dm is not None and dm[5] > 0:
-            o, tape = self._torch_attention(qkv, mode, dm[5], dm[6])
-            lse = None
+        dm = self._drops(pre, sub)
+        o, lse = self._t(M, C), self._f(M, cfg.H)
+        if dm is not None and dm[5] > 0:      # attn_drop: the counter-based mask is applied to the probabilities inside the kernel
+            ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode, drop=(dm[5], dm[6]))
         else:
-            o, lse = self._t(M, C), self._f(M, cfg.H)
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
         y = self._f(M, C)
         ops.gemm_nt(self._mm(o), self.Wn[f'{pre}.{attn}.proj'], P[f'{pre}.{attn}.proj.bias'], EPI_RESID, resid=x, out_f=y)
         if dm is not None and (dm[0] > 0 or dm[3] > 0):      # proj_drop + DropPath on the branch (DSTformer.py:148-149,241)
             ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])
         if self.fold:      # backward needs xhat and rstd only: the fp32 sub-layer input is not kept
-            sv = dict(x=None, mean=None, rstd=rstd, xn=xn, qkv=qkv, o=o, lse=lse, dm=dm, tape=tape) if need_grad else None
+            sv = dict(x=None, mean=None, rstd=rstd, xn=xn, qkv=qkv, o=o, lse=lse, dm=dm) if need_grad else None
         else:
-            sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, qkv=qkv, o=o, lse=lse, dm=dm, tape=tape) if need_grad else None
+            sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, qkv=qkv, o=o, lse=lse, dm=dm) if need_grad else None
         return y, sv
 
     def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1):
@@ -544,11 +521,8 @@ class Engine:
                                cfg.scale, mode)
             del do
             return self._fold_tail(dqkv, part, sv, lin, f'{pre}.{norm}', dy, extra, need_t)
-        if sv.get('tape') is not None:                        # torch fallback of the attention core (attn_drop > 0)
-            leaf, o32 = sv['tape']
-            (dq32,) = torch.autograd.grad(o32, leaf, do.float())
-            dqkv.copy_(dq32)
-            del dq32
+        if dm is not None and dm[5] > 0:
+            ops.attn_bwd(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode, drop=(dm[5], dm[6]))
         else:
             ops.attn_bwd(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
         del do

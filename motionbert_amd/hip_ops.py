@@ -49,6 +49,8 @@ SIGNATURES = {
     'mbx_gemm_tn_x3': (_i, [_vp] * 6 + [_i, _i, _i, _vp, _vp]),
     'mbx_attn_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'mbx_attn_bwd': (_i, [_vp] * 5 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'mbx_attn_fwd_drop': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _f, C.c_uint64, _vp]),
+    'mbx_attn_bwd_drop': (_i, [_vp] * 5 + [_i, _i, _i, _i, _i, _f, _i, _i, _f, C.c_uint64, _vp]),
     'mbx_attn_bwd_stats': (_i, [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
     'mbx_fuse_fwd': (_i, [_vp] * 6 + [_i, _i, _vp]),
     'mbx_fuse_ln_fwd': (_i, [_vp] * 12 + [_f] + [_vp] * 2 + [_i] * 3 + [_vp]),
@@ -316,13 +318,22 @@ class HipOps:
         self._ck(self.lib.mbx_gemm_tn(_p(dy_t), _p(a_t), _p(dw), _p(db), M, N, K, _DT[dy_t.dtype], _p(ws), self._stream()))
 
     # ------------------------------------------------------------------ attention
-    def attn_fwd(self, qkv, o, lse, B, T, J, H, scale, mode):
+    def attn_fwd(self, qkv, o, lse, B, T, J, H, scale, mode, drop=None):
+        """drop = (p, seed): nn.Dropout(p) on the probabilities inside the kernel (counter-based mask, dropmask.py)."""
         hd = o.shape[-1] // H
+        if drop is not None and drop[0] > 0:
+            self._ck(self.lib.mbx_attn_fwd_drop(_p(qkv), _p(o), _p(lse), B, T, J, H, hd, float(scale), int(mode), _DT[qkv.dtype],
+                                                float(drop[0]), int(drop[1]), self._stream()))
+            return
         self._ck(self.lib.mbx_attn_fwd(_p(qkv), _p(o), _p(lse), B, T, J, H, hd, float(scale), int(mode), _DT[qkv.dtype],
                                        self._stream()))
 
-    def attn_bwd(self, qkv, o, do, lse, dqkv, B, T, J, H, scale, mode):
+    def attn_bwd(self, qkv, o, do, lse, dqkv, B, T, J, H, scale, mode, drop=None):
         hd = o.shape[-1] // H
+        if drop is not None and drop[0] > 0:
+            self._ck(self.lib.mbx_attn_bwd_drop(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, J, H, hd, float(scale), int(mode),
+                                                _DT[qkv.dtype], float(drop[0]), int(drop[1]), self._stream()))
+            return
         self._ck(self.lib.mbx_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, J, H, hd, float(scale), int(mode),
                                        _DT[qkv.dtype], self._stream()))
 

@@ -259,25 +259,39 @@ class MockOps:
         q5 = qkv.float().reshape(B, T, J, 3, H, C // H)
         return q5[:, :, :, 0], q5[:, :, :, 1], q5[:, :, :, 2]
 
-    def attn_fwd(self, qkv, o, lse, B, T, J, H, scale, mode):
-        self._log(f'attn_fwd.{mode}')
+    @staticmethod
+    def _attn_mask(p, mode, drop):
+        """keep / (1 - p) on the probabilities, over the flat index of the REFERENCE's attn tensor: [B T, H, J, J] (spatial,
+        DSTformer.py:180) is this [B,T,H,J,J] flattened; [B, H, J, T, T] (temporal, :194) is this [B,J,H,T,T] with J and H swapped."""
+        from motionbert_amd.dropmask import mask_like
+        if drop is None or drop[0] <= 0:
+            return None
+        if mode == MODE_SPATIAL:
+            return mask_like(p, drop[0], drop[1])
+        return mask_like(p.permute(0, 2, 1, 3, 4).contiguous(), drop[0], drop[1]).permute(0, 2, 1, 3, 4)
+
+    def attn_fwd(self, qkv, o, lse, B, T, J, H, scale, mode, drop=None):
+        self._log(f'attn_fwd.{mode}' + ('.drop' if drop is not None and drop[0] > 0 else ''))
         q, k, v = self._split(qkv, B, T, J, H)
         if mode == MODE_SPATIAL:
             s = torch.einsum('btihd,btjhd->bthij', q, k) * scale
             l = torch.logsumexp(s, -1)                      # [B,T,H,J]
             p = torch.exp(s - l[..., None])
-            oo = torch.einsum('bthij,btjhd->btihd', p, v)
+            m = self._attn_mask(p, mode, drop)
+            oo = torch.einsum('bthij,btjhd->btihd', p if m is None else p * m, v)
             lse.copy_(l.permute(0, 1, 3, 2).reshape(lse.shape))
         else:
             s = torch.einsum('bsjhd,btjhd->bjhst', q, k) * scale
             l = torch.logsumexp(s, -1)                      # [B,J,H,T]
             p = torch.exp(s - l[..., None])
-            oo = torch.einsum('bjhst,btjhd->bsjhd', p, v)
+            m = self._attn_mask(p, mode, drop)
+            oo = torch.einsum('bjhst,btjhd->bsjhd', p if m is None else p * m, v)
             lse.copy_(l.permute(0, 3, 1, 2).reshape(lse.shape))
         o.copy_(oo.reshape(o.shape).to(o.dtype))
 
-    def attn_bwd(self, qkv, o, do, lse, dqkv, B, T, J, H, scale, mode):
-        self._log(f'attn_bwd.{mode}')
+    def attn_bwd(self, qkv, o, do, lse, dqkv, B, T, J, H, scale, mode, drop=None):
+        """with `drop`: dP = mask (dO V^T), dV from the dropped probabilities, delta = rowsum(dO o) as ever (o carries the mask)."""
+        self._log(f'attn_bwd.{mode}' + ('.drop' if drop is not None and drop[0] > 0 else ''))
         q, k, v = self._split(qkv, B, T, J, H)
         hd = q.shape[-1]
         do5 = do.float().reshape(B, T, J, H, hd)
@@ -288,19 +302,27 @@ class MockOps:
         if mode == MODE_SPATIAL:
             s = torch.einsum('btihd,btjhd->bthij', q, k) * scale
             p = torch.exp(s - l4.permute(0, 1, 3, 2)[..., None])
+            m = self._attn_mask(p, mode, drop)
             dp = torch.einsum('btihd,btjhd->bthij', do5, v)
+            pd = p
+            if m is not None:
+                dp, pd = dp * m, p * m
             ds = p * (dp - delta.permute(0, 1, 3, 2)[..., None]) * scale
             out[:, :, :, 0] = torch.einsum('bthij,btjhd->btihd', ds, k)
             out[:, :, :, 1] = torch.einsum('bthij,btihd->btjhd', ds, q)
-            out[:, :, :, 2] = torch.einsum('bthij,btihd->btjhd', p, do5)
+            out[:, :, :, 2] = torch.einsum('bthij,btihd->btjhd', pd, do5)
         else:
             s = torch.einsum('bsjhd,btjhd->bjhst', q, k) * scale
             p = torch.exp(s - l4.permute(0, 2, 3, 1)[..., None])
+            m = self._attn_mask(p, mode, drop)
             dp = torch.einsum('bsjhd,btjhd->bjhst', do5, v)
+            pd = p
+            if m is not None:
+                dp, pd = dp * m, p * m
             ds = p * (dp - delta.permute(0, 2, 3, 1)[..., None]) * scale
             out[:, :, :, 0] = torch.einsum('bjhst,btjhd->bsjhd', ds, k)
             out[:, :, :, 1] = torch.einsum('bjhst,bsjhd->btjhd', ds, q)
-            out[:, :, :, 2] = torch.einsum('bjhst,bsjhd->btjhd', p, do5)
+            out[:, :, :, 2] = torch.einsum('bjhst,bsjhd->btjhd', pd, do5)
         dqkv.copy_(out.reshape(dqkv.shape).to(dqkv.dtype))
 
     # fusion ----------------------------------------------------------------

@@ -345,6 +345,39 @@ def test_attention(ops, dt, mode, B, T, H, hd):
         check(f'attn_bwd.{n}.{tag}', dq[:, i * C:(i + 1) * C], dq2[:, i * C:(i + 1) * C], 5e-5 if dt == torch.float32 else 2e-2, floor)
 
 
+@pytest.mark.parametrize('dt', TD)
+@pytest.mark.parametrize('mode,B,T,H,hd', [(MODE_SPATIAL, 3, 9, 4, 32), (MODE_SPATIAL, 2, 5, 8, 64), (MODE_TEMPORAL, 2, 27, 4, 64),
+                                           (MODE_TEMPORAL, 2, 81, 4, 32), (MODE_TEMPORAL, 1, 243, 8, 64), (MODE_TEMPORAL, 2, 100, 2, 64)])
+def test_attention_probability_dropout(ops, dt, mode, B, T, H, hd):
+    """nn.Dropout on the softmax output (attn_drop, DSTformer.py:96,182,196) INSIDE the attention kernels: forward and backward
+    with the counter-based mask against the torch restatement that multiplies the materialised probabilities by
+    dropmask.mask_like over the reference's attn tensor layout (and that tests/test_host_logic.py pins to the real reference
+    run with forced masks).  Every kernel family: one wave per short problem, shared tiles for long ones, the dQ + dK/dV pair."""
+    J, C = 17, H * hd
+    M = B * T * J
+    qkv = rnd(M, 3 * C, seed=1, dtype=dt)
+    qkv[:, :C] *= 2.0
+    scale = hd ** -0.5
+    drop = (0.25, 0x1234567890ABCDEF)
+    tol_o = 2e-5 if dt == torch.float32 else 1.5e-2
+    tag = f'{tname(dt)}.{"sp" if mode == MODE_SPATIAL else "tm"}.B{B}T{T}H{H}d{hd}'
+    o, lse = torch.full((M, C), 9.0, device=DEV, dtype=dt), torch.full((M, H), 9.0, device=DEV)
+    o2, lse2 = torch.empty(M, C, device=DEV, dtype=dt), torch.empty(M, H, device=DEV)
+    o0 = torch.empty(M, C, device=DEV, dtype=dt)
+    ops.attn_fwd(qkv, o, lse, B, T, J, H, scale, mode, drop=drop)
+    ops.attn_fwd(qkv, o0, torch.empty_like(lse), B, T, J, H, scale, mode)
+    MockOps().attn_fwd(qkv, o2, lse2, B, T, J, H, scale, mode, drop=drop)
+    check(f'attn_drop.fwd.o.{tag}', o, o2, tol_o)
+    check(f'attn_drop.fwd.lse.{tag}', lse, lse2, 2e-5 if dt == torch.float32 else 1e-4)
+    assert rel(o.float(), o0.float()) > 0.1, 'the mask must change the output'
+    do = rnd(M, C, seed=2, dtype=dt)
+    dq, dq2 = torch.full((M, 3 * C), 9.0, device=DEV, dtype=dt), torch.empty(M, 3 * C, device=DEV, dtype=dt)
+    ops.attn_bwd(qkv, o2, do, lse2, dq, B, T, J, H, scale, mode, drop=drop)
+    MockOps().attn_bwd(qkv, o2, do, lse2, dq2, B, T, J, H, scale, mode, drop=drop)
+    for i, n in enumerate(['dq', 'dk', 'dv']):
+        check(f'attn_drop.bwd.{n}.{tag}', dq[:, i * C:(i + 1) * C], dq2[:, i * C:(i + 1) * C], 5e-5 if dt == torch.float32 else 2e-2)
+
+
 # ---------------------------------------------------------------------------------------------- memory safety
 class Guarded:
     """Output/workspace buffers carved out of a larger allocation with sentinel bands on both sides: a kernel
