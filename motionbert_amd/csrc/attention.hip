@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
     constexpr int KP = 32;
     constexpr int RSTR = rm_stride<T>(HD);
     constexpr int TILE = KP * RSTR;
-    constexpr int PER = 4 * TILE + 2 * KP * 4 + 6 * HD * 4;      // four tiles, lse / delta, the row-dot vectors (stats variant)
+    constexpr int PER = 4 * TILE + 2 * KP * 4;      // four tiles, lse / delta (74.75 KB per workgroup at hd = 64: two workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, i = lane & 31;
     const int C = H * HD, C3 = 3 * C;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
     char* dot_ = vt + TILE;
     float* lse_s = reinterpret_cast<float*>(dot_ + TILE);
     float* del_s = lse_s + KP;
-    uint4* vec = reinterpret_cast<uint4*>(del_s + KP);
+    uint4* vec = reinterpret_cast<uint4*>(dot_);      // row-dot vectors (stats variant): they move into the dO tile once it is dead
     const bool stats = sizeof(T) == 2 && st_part != nullptr;      // wave-uniform
     const size_t rstride = (size_t)P.tstep * C3, ostride = (size_t)P.tstep * C;
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
@@ -592,7 +592,13 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
     fill_two<T, HD>(qt, qbase, rstride, kt, qbase + C, rstride, RSTR, P.L, KP, lane, 64);
     fill_two<T, HD>(vt, qbase + 2 * C, rstride, dot_, dobase, ostride, RSTR, P.L, KP, lane, 64);
-    if (stats) fill_stat_vec<HD>(vec, st_rsum, st_bias, C, P.h, lane, 64);
+    uint4 vec_reg = make_uint4(0u, 0u, 0u, 0u);      // this lane's entry of the row-dot vectors (3 hd / 4 <= 48 entries), parked in registers
+    if (stats && lane < 3 * HD / 4) {
+        const int j = lane / (HD / 4), d = (lane % (HD / 4)) * 4;
+        const float4 r = *reinterpret_cast<const float4*>(st_rsum + j * C + P.h * HD + d);
+        const float4 b = *reinterpret_cast<const float4*>(st_bias + j * C + P.h * HD + d);
+        vec_reg = make_uint4(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w), pack_bf2(-b.x, -b.y), pack_bf2(-b.z, -b.w));
+    }
     {   // per-row statistics: lse and delta = sum_d dO * O (one row per lane, all loads in flight together)
         const int q = lane;
         if (q < KP) {
@@ -682,7 +688,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
         if constexpr (sizeof(T) == 2) {
             if (stats) {
                 // all four tiles are dead as operands; q, k, v are still intact: dq -> Q tile, dk -> K tile, dv -> V tile, each
-                // lane taking the two dots of its row fragment with the values it overwrites
+                // lane taking the two dots of its row fragment with the values it overwrites (vectors: into the dead dO tile first;
+                // wave-private LDS executes in order, no barrier)
+                if (lane < 3 * HD / 4) vec[lane] = vec_reg;
                 float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
                 store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(qt + (size_t)i * RSTR), dq, g, vec, a1, a2);
                 store_rowfrag_dot<HD>(reinterpret_cast<bf16_t*>(kt + (size_t)i * RSTR), dk, g, vec + HD / 4, b1, b2);
@@ -1052,7 +1060,7 @@ static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
     hipStream_t s = (hipStream_t)stream;
 #ifndef MBX_ATTN_BWD_TWO_KERNELS      // A/B builds only (tools/build_variants.py): force the dQ + dK/dV kernel pair
     if (shared && dtype == MBX_BF16 && !dr.thresh) {   // dropout: the dQ + dK/dV pair below (this kernel sits at its 128-VGPR budget: the mask hash spills)
-        const size_t shm = (size_t)4 * KP * rm_stride<bf16_t>(hd) + 2 * KP * 4 + 6 * hd * 4;
+        const size_t shm = (size_t)4 * KP * rm_stride<bf16_t>(hd) + 2 * KP * 4 + 3 * hd * 4;      // + the row-dot vectors (stats variant)
         if (shm <= 160 * 1024) {
 #define MBX_BWD_FUSED(HDV)                                                                                            \
     do {                                                                                                              \
@@ -1071,7 +1079,7 @@ static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
     if (!shared) {
 #define MBX_BWD_SMALL2(TT, HDV, DR)                                                                                   \
     do {                                                                                                              \
-        const size_t shm = (size_t)4 * (4 * 32 * rm_stride<TT>(HDV) + 2 * 32 * 4 + 6 * HDV * 4);                      \
+        const size_t shm = (size_t)4 * (4 * 32 * rm_stride<TT>(HDV) + 2 * 32 * 4);                                    \
         auto k = attn_bwd_small_kernel<TT, HDV, DR>;                                                                  \
         if (set_lds(k, shm, "attn_bwd_small")) return 1;                                                              \
         hipLaunchKernelGGL(k, dim3((nprob + 3) / 4), dim3(256), shm, s, (const TT*)qkv, (const TT*)o, (const TT*)d_o, lse, \
