@@ -251,9 +251,13 @@ class DSTformer(nn.Module):
         #: statistics; the throughput mode), 'bf16x3' (split-operand bf16 MFMA, fp32-class: meets the 1e-3 gate at about a
         #: third of the bf16 GEMM rate) or 'fp32' (exact fp32 MFMA; the reference parity mode)
         self.precision = os.environ.get('MBX_PRECISION', 'bf16')
-        #: low-memory training: rebuild LayerNorm outputs and MLP post-activations in backward instead of saving them (one extra
-        #: element-wise launch per sub-layer; 14 -> 9 bytes of saved activations per residual element on average)
+        #: low-memory training: rebuild the MLP post-activations (and, without LayerNorm folding, the LayerNorm outputs) in backward
+        #: instead of saving them (one extra element-wise launch each; 256 clips x 243 frames then train inside one MI355X)
         self.recompute = False
+        #: LayerNorm folding (bf16, no dropout): the affine part of every Block LayerNorm lives in the qkv / fc1 weights and its
+        #: backward runs as the epilogue of the dX GEMM (engine.py, include/mbx.h).  False selects the plain sequencing (the A/B
+        #: switch of the measurements; the fp32-class modes and training with dropout use the plain sequencing anyway).
+        self.fold_ln = True
         self.joints_embed = nn.Linear(dim_in, dim_feat)
         self.pos_drop = nn.Dropout(p=drop_rate)
         dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
