@@ -682,6 +682,11 @@ def main():
                     hbm_tb_s=round(hbm_tbs, 3) if hbm_tbs else None, hbm_frac=round(hbm_tbs / HBM_PEAK_TBS, 4) if hbm_tbs else None,
                     hbm_frac_of_achievable=round(hbm_tbs / HBM_ACHIEVABLE_TBS, 4) if hbm_tbs else None,
                     attainable_tflops=round(min(peak, intensity * HBM_ACHIEVABLE_TBS), 1) if intensity else None, dominant_by_time=dom)
+        # the same figure per C-ABI GEMM entry: since round 3 the family above also carries what used to be stand-alone HBM passes
+        # (the LayerNorm backward is the epilogue of mbx_gemm_nt_lnbwd), so its FLOP rate dropped while the step got shorter
+        roof['by_entry'] = {k: dict(launches=agg[k]['calls'], ms=round(agg[k]['ms'], 3), tflops=round(agg[k]['flops'] / (agg[k]['ms'] * 1e-3) / 1e12, 1),
+                                    frac=round(agg[k]['flops'] / (agg[k]['ms'] * 1e-3) / 1e12 / peak, 4))
+                            for k in NT_FAMILY + ('gemm_tn',) if k in agg and agg[k]['ms'] > 0}
     flops_step = wl_flops if wl_flops is not None else 3.0 * model_flops_fwd(FULL, T) * B
     out = {
         'metric': 'clips/sec [B,243,17,3] DSTformer fwd+bwd', 'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world,
