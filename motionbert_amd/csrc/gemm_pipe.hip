@@ -1175,6 +1175,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __re
 // (the 256 x 128 kernel saturates the LDS: 64 ds_read_b64_tr_b16 per wave per 16 MFMAs) and 1/3 less LDS-DMA.
 // ================================================================================================
 static constexpr int U_BN = 256, U_BK = 256, U_BMS = 32;
+// A/B knobs of the weight-gradient GEMM's operand traffic (tools/build_variants.py; the product build uses the defaults):
+//   MBX_TN_AHEAD  chunks in flight behind the one being multiplied (3; 2 = a smaller L2 footprint per workgroup)
+//   MBX_TN_ORDER  0: the k tiles of an n panel are consecutive workgroups; 1: the n tiles of a k panel
+//   MBX_TN_AUX    cache-policy bits of the LDS-DMA loads (0 default, 2 = nt)
+#ifndef MBX_TN_AHEAD
+#define MBX_TN_AHEAD 3
+#endif
+#ifndef MBX_TN_ORDER
+#define MBX_TN_ORDER 0
+#endif
+#ifndef MBX_TN_AUX
+#define MBX_TN_AUX 0
+#endif
+#define GLDS16_TN(src, dst) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src), (lds_void_t*)(dst), 16, 0, MBX_TN_AUX)
 static constexpr int U_TILE = U_BMS * 512, U_STAGE = 2 * U_TILE;   // 16 KiB per operand tile, 32 KiB per stage
 
 // X3 (precision 'bf16x3'): dW = dY_hi^T A_hi + dY_hi^T A_lo + dY_lo^T A_hi, the three passes laid end to end as ONE token
@@ -1190,7 +1204,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int split = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
     if (split >= nsplits) return;
+#if MBX_TN_ORDER == 1
+    const int ntn_ = ntiles / ntk;
+    const int n0 = (tile % ntn_) * U_BN, k0 = (tile / ntn_) * U_BK;
+#else
     const int n0 = (tile / ntk) * U_BN, k0 = (tile % ntk) * U_BK;
+#endif
     const int wr = wave >> 2, wc = wave & 3;   // wave tile: n rows [128 wr, +128), k cols [64 wc, +64)
     const int nchunks1 = (M + U_BMS - 1) / U_BMS;          // chunks of one pass
     const int nchunks = X3 ? 3 * nchunks1 : nchunks1;
@@ -1217,8 +1236,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
         const bf16_t* as_ = (p1_ && !p2_) ? A_lo : A;                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                           \
             const size_t r_ = (size_t)min(mb_ + rowv[i_], M - 1);                                    \
-            GLDS16(ys_ + r_ * N + ycol[i_], dstY + (stage_) * U_STAGE + i_ * 1024);                  \
-            GLDS16(as_ + r_ * K + acol[i_], dstA + (stage_) * U_STAGE + i_ * 1024);                  \
+            GLDS16_TN(ys_ + r_ * N + ycol[i_], dstY + (stage_) * U_STAGE + i_ * 1024);               \
+            GLDS16_TN(as_ + r_ * K + acol[i_], dstA + (stage_) * U_STAGE + i_ * 1024);               \
         }                                                                                            \
     } while (0)
 
@@ -1240,8 +1259,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     const bool trailing = wave >= 4;
     if (nc > 0) U_ISSUE(c_beg, 0);
     if (nc > 1) U_ISSUE(c_beg + 1, 1);
+#if MBX_TN_AHEAD == 3
     if (nc > 2) U_ISSUE(c_beg + 2, 2);
     if (nc > 2) WAIT_VMCNT(8); else if (nc > 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);
+#else
+    if (nc > 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);
+#endif
     __builtin_amdgcn_s_barrier();
     if (trailing) __builtin_amdgcn_s_barrier();
     bf16x8_t fy[2][4], fa[2][2];
@@ -1284,11 +1307,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
         const int vc = c_beg + c;
         U_READ(stage, vc);
         // own share of chunk c+1 landed (c+2 may fly); the fragments have arrived (asm reads: nothing may touch them earlier)
+#if MBX_TN_AHEAD == 3
         if (nc - 1 - c >= 2) {
             TR_WAIT6("vmcnt(4) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
         } else {
             TR_WAIT6("vmcnt(0) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
         }
+#else
+        TR_WAIT6("vmcnt(0) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);   // only chunk c+1 is outstanding
+#endif
         TR_WAIT6("lgkmcnt(0)", fy[1][0], fy[1][1], fy[1][2], fy[1][3], fa[1][0], fa[1][1]);
         U_FIX(vc);
         // X3: pass 1 streams dY_hi a second time -> it must not count twice in the bias gradient
@@ -1304,7 +1331,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
                 }
         }
         U_BARRIER();
-        if (c + 3 < nc) U_ISSUE(vc + 3, (stage + 3) & 3);
+        if (c + MBX_TN_AHEAD < nc) U_ISSUE(vc + MBX_TN_AHEAD, (stage + MBX_TN_AHEAD) & 3);
         U_MMA();
         U_BARRIER();
         stage = (stage + 1) & 3;

@@ -551,6 +551,13 @@ class Engine:
         if db is None:                     # qkv_bias=False: the column sums of dY are still needed for d(beta)
             db = self._f(dY.shape[1])
         ws = self._wstream()
+        dx_first = os.environ.get('MBX_FOLD_ORDER', '0') == '1'      # A/B: the dX GEMM (critical path) before the weight gradient
+        if dx_first:
+            dx = self._f(M, C)
+            dx_t = self._t(M, C) if need_t else None
+            if callable(extra):
+                extra = extra()
+            ops.gemm_nt_lnbwd(dY, self.Wt[lin], sv['xn'], rowc, dy, extra, dx, dx_t)
         if ws is None:
             ops.gemm_tn(dY, sv['xn'], G[lin + '.weight'], db)
             ops.unfold_norm_grads(G[lin + '.weight'], db, P[lin + '.weight'], P[norm + '.weight'], P[norm + '.bias'],
@@ -563,6 +570,8 @@ class Engine:
                                       G[norm + '.weight'], G[norm + '.bias'])
             for t in (dY, sv['xn'], db):
                 t.record_stream(ws)
+        if dx_first:
+            return dx, dx_t
         dx = self._f(M, C)
         dx_t = self._t(M, C) if need_t else None
         if callable(extra):      # dual-stream backward: the other block's input gradient, awaited only now
