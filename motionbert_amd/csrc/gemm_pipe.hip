@@ -1248,10 +1248,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // bias gradient = column sums of dY: the k-tile-0 workgroups' wave-column 0 adds up its dY fragments on the VALU (a lane
-    // of a transposed fragment holds 8 tokens of ONE column): 4 floats per lane instead of four more 32 x 32 accumulators
-    const bool want_db = (part_b != nullptr) && (k0 == 0) && (wc == 0);
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // bias gradient = column sums of dY (a lane of a transposed fragment holds 8 tokens of ONE column).  Round 3 finding: in
+    // round 2 wave column 0 of the k-tile-0 workgroups summed all four fragments of its wave row on the VALU (~130 operations in
+    // the read phase) -- and the kernel WITHOUT a bias gradient measured 18-22 % faster (dW_qkv 0.634 -> 0.518 ms, -DMBX_TN_NODB):
+    // what costs is not the work but its imbalance.  The slow waves hold their workgroup back at both barriers of every chunk, and
+    // the slow workgroup falls behind the k tiles that stream the same dY panel, so the panel is fetched from HBM again instead
+    // of found in L2.  Now the work is EVEN: the ntk k-tile workgroups of an n panel and the four waves of a wave row hold the
+    // same dY fragments, so wave (wr, wc) of k tile kt sums fragment wc of ONE 16-token step (ntk = 2: step kt; ntk = 4: half of the
+    // dwords of step kt & 1; ntk = 1: both steps) as packed-bf16 dots with ones -- 4 (8) VALU operations per chunk in every wave of
+    // every workgroup -- into its own partial slot; the slots are folded with the token splits.  (Also measured: the same dots in
+    // the MFMA phase 0.602 ms -- v_dot2c beside MFMAs is expensive --, two extra ones-MFMAs per wave 0.640 ms.)
+#ifdef MBX_TN_NODB
+    const int nslot = 0;
+#else
+    const int nslot = part_b == nullptr ? 0 : (ntk == 2 || ntk == 4) ? ntk : 1;       // partial slots per token split
+#endif
+    const int kt_ = k0 / U_BK;
+    const bool want_db = nslot > 0 && (nslot > 1 || kt_ == 0);
+    const int db_s = nslot == 1 ? 0 : (kt_ & 1);                                       // this workgroup's 16-token step (nslot = 1: both)
+    uint32_t one_e[4];                                                                 // bf16 {1, 1} on this workgroup's dwords, 0 elsewhere
+#pragma unroll
+    for (int e = 0; e < 4; ++e) one_e[e] = (nslot == 4 && (e >> 1) != (kt_ >> 1)) ? 0u : 0x3f803f80u;
+    float bsum = 0.f;
 
     // Ping-pong schedule (see gemm_nt_pp256): waves 4-7 run one phase behind waves 0-3; phase R = the 12 transposed
     // fragments of a 32-token chunk -> registers (24 ds_read_b64_tr_b16), phase M = its 16 (+4 for the bias gradient) MFMAs
@@ -1301,6 +1319,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
                 _Pragma("unroll") for (int tc_ = 0; tc_ < 2; ++tc_)                                                  \
                     acc[tr_][tc_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[s_][tr_], fa[s_][tc_], acc[tr_][tc_], 0, 0, 0); \
     } while (0)
+#define U_DB1(s_, t_)                                                                                                \
+    do {                                                                                                             \
+        union { bf16x8_t v; uint32_t u[4]; } z_;                                                                     \
+        z_.v = fy[s_][t_];                                                                                           \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) bsum = dot2_bf16(z_.u[e_], one_e[e_], bsum);                \
+    } while (0)
 #define U_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
     int stage = 0;
     for (int c = 0; c < nc; ++c) {
@@ -1318,17 +1342,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
 #endif
         TR_WAIT6("lgkmcnt(0)", fy[1][0], fy[1][1], fy[1][2], fy[1][3], fa[1][0], fa[1][1]);
         U_FIX(vc);
-        // X3: pass 1 streams dY_hi a second time -> it must not count twice in the bias gradient
-        if (want_db && !(X3 && vc >= nchunks1 && vc < 2 * nchunks1)) {
-#pragma unroll
-            for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-                for (int t_ = 0; t_ < 4; ++t_) {
-                    union { bf16x8_t v; uint32_t u[4]; } z;
-                    z.v = fy[s_][t_];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bsum[t_] += __uint_as_float(z.u[e] << 16) + __uint_as_float(z.u[e] & 0xffff0000u);
-                }
+        if (want_db && !(X3 && vc >= nchunks1 && vc < 2 * nchunks1)) {      // X3: pass 1 streams dY_hi a second time
+            // one wave-uniform jump per chunk: fragment wc of step db_s (and of the other step too when there is one slot)
+            switch (db_s * 4 + wc) {
+                case 0: U_DB1(0, 0); if (nslot == 1) U_DB1(1, 0); break;
+                case 1: U_DB1(0, 1); if (nslot == 1) U_DB1(1, 1); break;
+                case 2: U_DB1(0, 2); if (nslot == 1) U_DB1(1, 2); break;
+                case 3: U_DB1(0, 3); if (nslot == 1) U_DB1(1, 3); break;
+                case 4: U_DB1(1, 0); break;
+                case 5: U_DB1(1, 1); break;
+                case 6: U_DB1(1, 2); break;
+                default: U_DB1(1, 3); break;
+            }
         }
         U_BARRIER();
         if (c + MBX_TN_AHEAD < nc) U_ISSUE(vc + MBX_TN_AHEAD, (stage + MBX_TN_AHEAD) & 3);
@@ -1338,18 +1363,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     }
     if (!trailing) __builtin_amdgcn_s_barrier();
 #undef U_BARRIER
+#undef U_DB1
 #undef U_MMA
 #undef U_FIX
 #undef U_READ
 #undef U_ISSUE
     const int i = lane & 31, g = lane >> 5;
-    if (want_db) {     // lanes l and l + 32 hold the two token halves of column l of each 32-column fragment
-#pragma unroll
-        for (int tr = 0; tr < 4; ++tr) {
-            const float tot = wave_halves<WaveAdd>(bsum[tr]);
-            const int n = n0 + wr * 128 + tr * 32 + i;
-            if (g == 0 && n < N) part_b[(size_t)split * N + n] = tot;
-        }
+    if (want_db) {     // lanes l and l + 32 hold the two token halves of column l of the wave's fragment (columns 32 wc .. + 31 of its row block)
+        const float tot = wave_halves<WaveAdd>(bsum);
+        const int n = n0 + wr * 128 + wc * 32 + i;
+        if (g == 0 && n < N) part_b[((size_t)split * nslot + (nslot > 1 ? kt_ : 0)) * N + n] = tot;
     }
     float* pw = part_w + (size_t)split * N * K;
 #pragma unroll
@@ -1383,9 +1406,15 @@ static int tnp_splits(int M, int N, int K, bool x3 = false) {
     if (s < 1) s = 1;
     return s;
 }
+// partial bias-gradient rows per token split (the k tiles of an n panel share the work: see gemm_tn_pipe256_kernel)
+static int tn_db_slots(int N, int K) {
+    if (!tn_use256(N, K)) return 1;
+    const int ntk = (K + U_BK - 1) / U_BK;
+    return (ntk == 2 || ntk == 4) ? ntk : 1;
+}
 size_t mbx_gemm_tn_pipe_ws(int M, int N, int K) {
     const size_t sp = tnp_splits(M, N, K);
-    return (sp * N * K + sp * N) * sizeof(float) + 256;
+    return (sp * N * K + sp * 4 * N) * sizeof(float) + 256;
 }
 int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, void* ws, hipStream_t s) {
     const bool big = tn_use256(N, K);
@@ -1393,8 +1422,9 @@ int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db,
     const int splits = tnp_splits(M, N, K);
     const int nchunks = big ? (M + U_BMS - 1) / U_BMS : (M + T_BMS - 1) / T_BMS;
     const int cps = (nchunks + splits - 1) / splits;
+    const int slots = tn_db_slots(N, K);
     float* part_w = splits == 1 ? dw : (float*)ws;
-    float* part_b = db ? (splits == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
+    float* part_b = db ? (splits * slots == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
     if (big) {
         const size_t shm256 = 4 * U_STAGE;
         const int ntiles256 = ntn * ntk, groups256 = (splits + 7) / 8;
@@ -1403,10 +1433,8 @@ int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db,
                            (const bf16_t*)a, (const bf16_t*)nullptr, (const bf16_t*)nullptr, part_w, part_b, M, N, K, ntk, ntiles256,
                            splits, cps);
         MBX_LAUNCH_CHECK("gemm_tn_pipe256");
-        if (splits > 1) {
-            if (mbx_launch_colsum(part_w, splits, N * K, 0, N * K, dw, s)) return 1;
-            if (db && mbx_launch_colsum(part_b, splits, N, 0, N, db, s)) return 1;
-        }
+        if (splits > 1 && mbx_launch_colsum(part_w, splits, N * K, 0, N * K, dw, s)) return 1;
+        if (db && splits * slots > 1 && mbx_launch_colsum(part_b, splits * slots, N, 0, N, db, s)) return 1;
         return 0;
     }
     const size_t shm = 3 * T_STAGE;
@@ -1427,7 +1455,7 @@ int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db,
 // columns as in the bf16 kernel) but the 256 x 256 kernel is always used.
 size_t mbx_gemm_tn_x3_ws(int M, int N, int K) {
     const size_t sp = tnp_splits(M, N, K, true);
-    return (sp * N * K + sp * N) * sizeof(float) + 256;
+    return (sp * N * K + sp * 4 * N) * sizeof(float) + 256;
 }
 int mbx_launch_gemm_tn_x3(const void* dy_hi, const void* dy_lo, const void* a_hi, const void* a_lo, float* dw, float* db, int M, int N,
                           int K, void* ws, hipStream_t s) {
@@ -1435,17 +1463,16 @@ int mbx_launch_gemm_tn_x3(const void* dy_hi, const void* dy_lo, const void* a_hi
     const int splits = tnp_splits(M, N, K, true);
     const int nchunks = 3 * ((M + U_BMS - 1) / U_BMS);
     const int cps = (nchunks + splits - 1) / splits;
+    const int ntk_ = (K + U_BK - 1) / U_BK, slots = (ntk_ == 2 || ntk_ == 4) ? ntk_ : 1;
     float* part_w = splits == 1 ? dw : (float*)ws;
-    float* part_b = db ? (splits == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
+    float* part_b = db ? (splits * slots == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
     const size_t shm256 = 4 * U_STAGE;
     if (set_lds_attr(gemm_tn_pipe256_kernel<true>, shm256, "gemm_tn_x3")) return 1;
     const int ntiles256 = ntn * ntk, groups256 = (splits + 7) / 8;
     hipLaunchKernelGGL(gemm_tn_pipe256_kernel<true>, dim3(8 * groups256 * ntiles256), dim3(512), shm256, s, (const bf16_t*)dy_hi,
                        (const bf16_t*)a_hi, (const bf16_t*)dy_lo, (const bf16_t*)a_lo, part_w, part_b, M, N, K, ntk, ntiles256, splits, cps);
     MBX_LAUNCH_CHECK("gemm_tn_x3");
-    if (splits > 1) {
-        if (mbx_launch_colsum(part_w, splits, N * K, 0, N * K, dw, s)) return 1;
-        if (db && mbx_launch_colsum(part_b, splits, N, 0, N, db, s)) return 1;
-    }
+    if (splits > 1 && mbx_launch_colsum(part_w, splits, N * K, 0, N * K, dw, s)) return 1;
+    if (db && splits * slots > 1 && mbx_launch_colsum(part_b, splits * slots, N, 0, N, db, s)) return 1;
     return 0;
 }
