@@ -29,6 +29,34 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 #define GLDS16(src, dst) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src), (lds_void_t*)(dst), 16, 0, 0)
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// 16-byte output store of the GEMM epilogues.  POLICY 1 = non-temporal (`global_store_dwordx4 ... nt`): used by the bf16 store /
+// GELU epilogues of the 256x256 kernel, whose output stream (0.5-1.0 GB per launch, read next by another kernel from HBM anyway)
+// otherwise competes for the L2 lines the neighbouring tiles share their A / W panels through; measured -8 % on the qkv and
+// fc1 launches (0.559 -> 0.516 ms, 0.572 -> 0.525 ms), -1 % on the step; nothing or a loss on the residual / LayerNorm-backward /
+// GELU' epilogues, which keep plain stores (profiles/r03_store_policy.txt).
+typedef uint32_t epi_u32x4_t __attribute__((ext_vector_type(4)));
+template <int POLICY>
+__device__ __forceinline__ void epi_store16(void* p, const uint4& v) {
+    if (POLICY == 1) {
+        const epi_u32x4_t d = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(d, reinterpret_cast<epi_u32x4_t*>(p));
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+#ifndef MBX_ST_PP
+#define MBX_ST_PP 1     // bf16 store / GELU epilogue of the 256x256 kernel
+#endif
+#ifndef MBX_ST_DG
+#define MBX_ST_DG 0     // GELU' epilogue
+#endif
+#ifndef MBX_ST_RES
+#define MBX_ST_RES 0    // residual epilogue (fp32 stream)
+#endif
+#ifndef MBX_ST_LNB
+#define MBX_ST_LNB 0    // LayerNorm-backward epilogue
+#endif
+
 // erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below bf16 resolution);
 // erf(u / sqrt 2) and the Gaussian of GELU' share one exponential, exp(-u^2 / 2).
 __device__ __forceinline__ void erf_parts(float u, float& erf_v, float& gauss) {
@@ -96,7 +124,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = wave * 32 + i * 16 + lr;
-        srcA[i] = A + (size_t)min(m0 + row, M - 1) * K + ((lp ^ ((row >> 2) & 3)) << 3);
+        srcA[i] = A + (size_t)min(((dbg & 8) ? 0 : m0) + row, M - 1) * K + ((lp ^ ((row >> 2) & 3)) << 3);   // dbg 8: every tile reads row block 0 (L2-resident A)
     }
     {
         const int row = wave * 16 + lr;
@@ -230,14 +258,17 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
                         v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w;
                         v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
                     }
-                    *reinterpret_cast<float4*>(out_f + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(out_f + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    epi_store16<MBX_ST_LNB>(out_f + o, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+                    epi_store16<MBX_ST_LNB>(out_f + o + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
                     if (out_t)
-                        *reinterpret_cast<uint4*>(out_t + o) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                        epi_store16<MBX_ST_LNB>(out_t + o, make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])));
                 }
             }
 #undef LNB_LOAD
         }
+        TSTAMP(1 + nk * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSTAMP(2 + nk * 4);
         return;
     }
     const int ec = (lane & 7) * 4, erow0 = lane >> 3;
@@ -276,7 +307,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
                     store4<bf16_t>(out2_t + o, v);
                 } else if (EPI == MBX_EPI_RESID) {
                     v[0] += rr[p].x; v[1] += rr[p].y; v[2] += rr[p].z; v[3] += rr[p].w;
-                    store4<float>(out_f + o, v);
+                    epi_store16<MBX_ST_RES>(out_f + o, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
                 } else if (EPI == MBX_EPI_TANH) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
@@ -441,10 +472,10 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                 if (FULL || (m < M && n < N)) {     // FULL: the wave's whole 128 x 64 NTN/2 block is inside the matrix (no branches)
                     const size_t o = (size_t)m * N + n;
                     if (EPI == MBX_EPI_STORE) {
-                        *reinterpret_cast<uint4*>(out_t + o) = t1[p];
+                        epi_store16<MBX_ST_PP>(out_t + o, t1[p]);
                     } else {
-                        if (out_t) *reinterpret_cast<uint4*>(out_t + o) = t1[p];
-                        *reinterpret_cast<uint4*>(out2_t + o) = t2[p];
+                        if (out_t) epi_store16<MBX_ST_PP>(out_t + o, t1[p]);
+                        epi_store16<MBX_ST_PP>(out2_t + o, t2[p]);
                     }
                 }
             }
@@ -516,7 +547,7 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
                             q2 = dot2_bf16(r[e], uw[e], dot2_bf16(r[e], nbp[e], q2));
                         }
                     }
-                    *reinterpret_cast<uint4*>(out_t + o) = make_uint4(r[0], r[1], r[2], r[3]);
+                    epi_store16<MBX_ST_DG>(out_t + o, make_uint4(r[0], r[1], r[2], r[3]));
                 }
                 if (st_part) {     // wave-uniform; every lane takes part in the cross-lane steps
                     q1 += dpp_mov<0xB1>(q1, q1); q2 += dpp_mov<0xB1>(q2, q2);      // quad_perm [1,0,3,2]
@@ -903,7 +934,7 @@ int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int
     if (((mask256 >> epi) & 1) && N >= 256) return launch_nt256(a, w, bias, epi, out_t, out2_t, out_f, resid, aux, M, N, K, s);
     const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
-    const size_t shm = P_NSTAGE * P_STAGE;
+    const size_t shm = P_NSTAGE * P_STAGE + (size_t)mbx_env_int("MBX_NTP_LDS_PAD", 0) * 1024;   // diagnostics: padding -> one workgroup per CU
 #ifdef MBX_DIAG
     static const int dbg = mbx_env_int("MBX_DBG", 0);
     static long long* const trace = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
@@ -946,17 +977,18 @@ extern "C" int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat,
     MBX_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && K > 0 && K % 64 == 0, "gemm_nt_lnbwd: bad shape M=%d N=%d K=%d (N %% 8, K %% 64)", M, N, K);
     MBX_CHECK_ARG((reinterpret_cast<uintptr_t>(rowc) & 15) == 0, "gemm_nt_lnbwd: rowc must be 16-byte aligned");
     const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
-    const size_t shm = P_NSTAGE * P_STAGE;
+    const size_t shm = P_NSTAGE * P_STAGE + (size_t)mbx_env_int("MBX_NTP_LDS_PAD", 0) * 1024;
     hipStream_t s = (hipStream_t)stream;
 #ifdef MBX_DIAG
     static const int dbg = mbx_env_int("MBX_DBG", 0);
+    static long long* const trace = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
 #endif
     if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_LNBWD>, shm, "gemm_nt_lnbwd")) return 1;
     hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_LNBWD>), dim3((unsigned)ntn * ntm), dim3(512), shm, s, (const bf16_t*)a, (const bf16_t*)w,
                        (const float*)nullptr, (bf16_t*)dx_t, (bf16_t*)nullptr, dx, dres, (const bf16_t*)xhat, M, N, K, ntn,
                        reinterpret_cast<const float4*>(rowc), extra
 #ifdef MBX_DIAG
-                       , dbg, (long long*)nullptr
+                       , dbg, trace
 #endif
                        );
     MBX_LAUNCH_CHECK("gemm_nt_lnbwd");

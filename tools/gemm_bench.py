@@ -82,6 +82,25 @@ def main():
         res['nt.' + name] = dict(ms=round(ms, 4), tflops=round(tf, 1), err=err)
         print(f'nt {name:8s} M={M} N={N} K={K}: {ms:8.4f} ms  {tf:7.1f} TF/s  err={err}', flush=True)
         del a, w, out_t, out2, out_f, resid, aux
+    # dX GEMMs with the LayerNorm-backward epilogue (round 3): d(qkv) -> dx, d(fc1) -> dx
+    for name, N, K in [('lnb_qkv', 512, 1536), ('lnb_fc1', 512, 1024)]:
+        if only and name not in only:
+            continue
+        a, w = rnd(M, K).to(bf), (rnd(N, K) * 0.05).to(bf)
+        xhat, dres, rowc = rnd(M, N).to(bf), rnd(M, N), torch.rand(M, 4, generator=g).to(dev)
+        dx, dx_t = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev, dtype=bf)
+        ms = timeit(lambda: ops.gemm_nt_lnbwd(a, w, xhat, rowc, dres, None, dx, dx_t), args.iters)
+        tf = 2.0 * M * N * K / ms / 1e9
+        err = None
+        if args.check:
+            rows = torch.randint(0, M, (512,), generator=g).to(dev)
+            acc = a[rows].float() @ w.float().t()
+            rc = rowc[rows]
+            ref = dres[rows] + rc[:, 0:1] * acc - rc[:, 1:2] - xhat[rows].float() * rc[:, 2:3]
+            err = float((dx[rows] - ref).norm() / ref.norm())
+        res['nt.' + name] = dict(ms=round(ms, 4), tflops=round(tf, 1), err=err)
+        print(f'nt {name:8s} M={M} N={N} K={K}: {ms:8.4f} ms  {tf:7.1f} TF/s  err={err}', flush=True)
+        del a, w, xhat, dres, rowc, dx, dx_t
     tn = [('dW_qkv', 1536, 512), ('dW_proj', 512, 512), ('dW_fc1', 1024, 512), ('dW_fc2', 512, 1024)]
     for name, N, K in tn:
         if only and name not in only:
