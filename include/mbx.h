@@ -40,7 +40,8 @@ enum mbx_epilogue {
     MBX_EPI_RESID = 2, /* out_f = resid + acc + bias                  proj / fc2 + residual (:241-249)     */
     MBX_EPI_TANH  = 3, /* out_f = tanh(acc + bias)                    pre_logits fc + Tanh (:294-297,354)  */
     MBX_EPI_DGELU = 4, /* out_t = acc * gelu_erf'(aux_t)              backward of nn.GELU                  */
-    MBX_EPI_LNBWD = 5  /* internal to mbx_gemm_nt_lnbwd (LayerNorm backward as a GEMM epilogue); not accepted by mbx_gemm_nt */
+    MBX_EPI_LNBWD = 5, /* internal to mbx_gemm_nt_lnbwd (LayerNorm backward as a GEMM epilogue); not accepted by mbx_gemm_nt */
+    MBX_EPI_RESID_LN = 6 /* internal to mbx_gemm_nt_resid_ln (residual GEMM + the next LayerNorm forward); not accepted by mbx_gemm_nt */
 };
 
 enum mbx_attn_mode {
@@ -88,6 +89,20 @@ int mbx_gemm_nt(const void* a, const void* w, const float* bias, int epilogue, v
 size_t mbx_gemm_tn_ws(int M, int N, int K);
 int mbx_gemm_tn(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, int dtype,
                 void* ws, void* stream);
+
+/* ---- residual GEMM + the LayerNorm that reads its output (bf16 path) ------------------------------------------------------
+ * y[M,N] f32 = resid + a . w^T + bias (MBX_EPI_RESID: Block's x + attn(..) / x + mlp(..), DSTformer.py:241-249) and, from the
+ * same launch, the next sub-layer's nn.LayerNorm over the rows of y (:241-249 norm*_s / norm*_t; LayerNorm forward of :79-85's
+ * callers): xn bf16 [M,N], mean / rstd f32 [M].  gamma = beta = NULL: plain normalisation (folded path).  Arithmetic and results
+ * identical to mbx_gemm_nt(MBX_EPI_RESID) followed by mbx_layernorm_fwd; the row block's last column-tile workgroup normalises
+ * it out of L2.  N in {256, 512, 1024} (a full row), K % 64 == 0, y != resid.  ws: >= mbx_gemm_nt_resid_ln_ws(M) bytes.
+ * Valid where workgroups with equal blockIdx & 7 share an XCD: mbx_xcc_probe writes the XCC id of each of `nblocks` workgroups
+ * for the caller to check (hip_ops.can_fuse_resid_ln); the kernel verifies it again and traps instead of reading a stale row. */
+size_t mbx_gemm_nt_resid_ln_ws(int M);
+int mbx_gemm_nt_resid_ln(const void* a, const void* w, const float* bias, const float* resid, float* y, const float* gamma,
+                         const float* beta, float eps, void* xn, float* mean, float* rstd, int M, int N, int K, void* ws,
+                         void* stream);
+int mbx_xcc_probe(int* out, int nblocks, void* stream);
 
 /* ---- LayerNorm folded into the Linear it feeds (bf16 path) ---------------------------------------------------------------
  * Every norm1 / norm2 of a Block feeds exactly one Linear (DSTformer.py:241-249 -> Attention.qkv :143 / MLP.fc1 :80):

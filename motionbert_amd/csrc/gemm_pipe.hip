@@ -44,6 +44,35 @@ __device__ __forceinline__ void epi_store16(void* p, const uint4& v) {
         *reinterpret_cast<uint4*>(p) = v;
     }
 }
+// 16-byte streaming input of an epilogue (residual, dres, xhat, u): POLICY 1 = non-temporal load
+typedef float epi_f32x4_t __attribute__((ext_vector_type(4)));
+template <int POLICY>
+__device__ __forceinline__ float4 epi_load_f4(const float* p) {
+    if (POLICY == 1) {
+        const epi_f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const epi_f32x4_t*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+template <int POLICY>
+__device__ __forceinline__ uint4 epi_load_u4(const bf16_t* p) {
+    if (POLICY == 1) {
+        const epi_u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const epi_u32x4_t*>(p));
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    return *reinterpret_cast<const uint4*>(p);
+}
+// measured (profiles/r03_store_policy.txt, session W): non-temporal loads of the residual -4 % on proj (0.343 -> 0.328 ms), nothing
+// on fc2; of dres / xhat in the LayerNorm-backward epilogue +0-4 %; of u in the GELU' epilogue nothing
+#ifndef MBX_LD_RES
+#define MBX_LD_RES 1
+#endif
+#ifndef MBX_LD_LNB
+#define MBX_LD_LNB 0
+#endif
+#ifndef MBX_LD_DG
+#define MBX_LD_DG 0
+#endif
 #ifndef MBX_ST_PP
 #define MBX_ST_PP 1     // bf16 store / GELU epilogue of the 256x256 kernel
 #endif
@@ -90,17 +119,111 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 static constexpr int P_BM = 256, P_BN = 128, P_BK = 32, P_ROWB = 64;
 static constexpr int P_A_BYTES = P_BM * P_ROWB, P_W_BYTES = P_BN * P_ROWB, P_STAGE = P_A_BYTES + P_W_BYTES;  // 24 KiB
 static constexpr int P_NSTAGE = 3;
+// (Round 3, measured and dropped: BK = 64 for this kernel -- 128-byte row segments, i.e. whole cache lines per LDS-DMA request, half
+// the barriers, 3 x 48 KiB stages and therefore ONE workgroup per CU.  Correct; the DMA-only loop gains 16 % (0.436 -> 0.364 ms at
+// K = 1536), the kernels nothing: lnb_qkv 0.811 -> 0.812 ms, fc2 0.513 -> 0.550 ms, proj 0.347 -> 0.366 ms, step 130.7 -> 132.3 ms.
+// profiles/r03_ntp_ablation.txt)
 
 // rows of 64 B = four 16-byte chunks; chunk c of row r at physical chunk c ^ ((r >> 2) & 3)
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * P_ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
+// ---- LayerNorm forward as the TAIL of the residual GEMM (MBX_EPI_RESID_LN, round 3) -----------------------------------------
+// y = resid + a.Wt + b is the input of the next sub-layer's LayerNorm, and the ntn column tiles of a 256-row block finish within
+// microseconds of each other on CUs of ONE XCD (row-block-granular tile order below).  The last of them to finish normalises the
+// block's rows while they are still in that XCD's L2: the stand-alone LayerNorm launch (0.16 ms, 516 MB read back from HBM) goes
+// away.  Arithmetic = ln_fwd_row of elementwise.hip (two-pass, fp32), so xn / mean / rstd are bit-identical to the unfused pair.
+// Protocol: every wave waits for its stores (vmcnt(0)); barrier; thread 0 adds {1, xcc, xcc^2} to the row block's counter with ONE
+// atomic (count | sum << 8 | sum of squares << 16); the workgroup that sees count ntn - 1 is last.  Visibility needs no cache
+// maintenance BECAUSE all contributors share an L2 -- which the last workgroup verifies from the sums (all XCC ids equal its own,
+// else trap: never a silently stale row); the host enables the path only after mbx_xcc_probe confirmed the blockIdx -> XCD rule.
+// The CU's own L1 cannot hold a stale copy: it is invalid at kernel start and this kernel never read y before (y != resid is checked).
+struct NtLnTail {
+    float* mean;
+    float* rstd;
+    const float* gamma;     // NULL: plain normalisation (folded affine part)
+    const float* beta;
+    unsigned* cnt;          // [row blocks], zero on entry, zero on exit
+    float eps;
+};
+__device__ __forceinline__ unsigned mbx_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+    return v;
+}
+template <int VPL>
+__device__ __forceinline__ void ln_tail_row(const float4 (&raw)[VPL], const float (&g)[VPL][4], const float (&bt)[VPL][4], float eps,
+                                            float invC, bf16_t* __restrict__ xn, float* __restrict__ mean, float* __restrict__ rstd,
+                                            size_t row, int N, int lane) {
+    float v[VPL][4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        v[k][0] = raw[k].x; v[k][1] = raw[k].y; v[k][2] = raw[k].z; v[k][3] = raw[k].w;
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    const float mu = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[k][e] -= mu; q = fmaf(v[k][e], v[k][e], q); }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(v[k][e] * rs, g[k][e], bt[k][e]);
+        store4<bf16_t>(xn + row * N + (k * 64 + lane) * 4, o);
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+// rows [m0, min(m0 + 256, M)) of y -> xn / mean / rstd; wave w owns rows m0 + w + 8 j, four rows per step (all loads first)
+template <int VPL>
+__device__ __forceinline__ void ln_tail_block(const float* y, bf16_t* __restrict__ xn, const NtLnTail& ln, int m0, int M, int N,
+                                              int wave, int lane) {
+    float g[VPL][4], bt[VPL][4];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[k][e] = 1.f; bt[k][e] = 0.f; }
+        if (ln.gamma != nullptr) { load4<float>(ln.gamma + (k * 64 + lane) * 4, g[k]); load4<float>(ln.beta + (k * 64 + lane) * 4, bt[k]); }
+    }
+    const float invC = 1.0f / (float)N;
+    const int rows = min(P_BM, M - m0);
+    // software pipeline over the wave's 32 rows, G rows per step, fully unrolled: the loads of step s + 1 are in flight (in their own
+    // registers) while step s is reduced and stored, so a step costs one memory latency, not a store drain plus a load latency
+    constexpr int G = VPL >= 4 ? 2 : 4, NS = 32 / G;      // 64 registers of rows in flight whatever the row length
+    float4 raw[2][G][VPL];
+#define LN_TAIL_LOAD(buf_, step_)                                                                               \
+    _Pragma("unroll") for (int j_ = 0; j_ < G; ++j_) {                                                          \
+        const int r_ = min(wave + 8 * ((step_) * G + j_), rows - 1);                                            \
+        _Pragma("unroll") for (int k_ = 0; k_ < VPL; ++k_)                                                      \
+            raw[buf_][j_][k_] = *reinterpret_cast<const float4*>(y + (size_t)(m0 + r_) * N + (k_ * 64 + lane) * 4); \
+    }
+    LN_TAIL_LOAD(0, 0);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        if (st + 1 < NS) { LN_TAIL_LOAD((st + 1) & 1, st + 1); }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int r = wave + 8 * (st * G + j);
+            if (r < rows) ln_tail_row<VPL>(raw[st & 1][j], g, bt, ln.eps, invC, xn, ln.mean, ln.rstd, (size_t)(m0 + r), N, lane);
+        }
+    }
+#undef LN_TAIL_LOAD
+}
+
+// (Round 3, measured and dropped: a ninth PRODUCER wave per workgroup that issues all 24 LDS-DMA instructions of a k-tile, so
+// that no compute wave stalls on the vector-memory path in front of its MFMAs.  Correct, and 5-24 % slower on every shape
+// (lnb_qkv 0.777 -> 0.822 ms, proj 0.341 -> 0.424 ms): one wave issues the 24 instructions more slowly than eight waves issue
+// three each -- DMA-only loop 0.436 -> 0.490 ms -- and at 96 VGPRs the residual epilogue spills.  profiles/r03_ntp_ablation.txt)
 template <int EPI>
 __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ out_t,
                                                               bf16_t* __restrict__ out2_t, float* __restrict__ out_f,
                                                               const float* __restrict__ resid, const bf16_t* __restrict__ aux,
                                                               int M, int N, int K, int ntn, const float4* __restrict__ rowc,
-                                                              const float* __restrict__ extra
+                                                              const float* __restrict__ extra, const NtLnTail ln
 #ifdef MBX_DIAG
                                                               , int dbg, long long* trace
 #endif
@@ -111,8 +234,19 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 stages x 24 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lid = xcd_remap2(blockIdx.x, gridDim.x);
+    int lid;
+    if constexpr (EPI == MBX_EPI_RESID_LN) {
+        // row-block-granular order: XCD x (= blockIdx & 7) owns whole 256-row blocks, its workgroup `idx` is column tile idx % ntn of
+        // its row block idx / ntn; the grid is padded to 8 * ntn * ceil(row blocks / 8) workgroups
+        const int nrb = (M + P_BM - 1) / P_BM, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nrb >> 3, r = nrb & 7, rbl = idx / ntn;
+        if (rbl >= q + (xcd < r ? 1 : 0)) return;
+        lid = ((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + rbl) * ntn + idx % ntn;
+    } else {
+        lid = xcd_remap2(blockIdx.x, gridDim.x);
+    }
     const int n0 = (lid % ntn) * P_BN, m0 = (lid / ntn) * P_BM;
+    const int nk = K / P_BK;
     const int wm = wave >> 1, wn = wave & 1;
 
     // LDS-DMA assignment: one instruction = 16 rows x 64 B.  wave w fills A rows [32 w, 32 w + 32) (2 instr)
@@ -141,7 +275,6 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = K / P_BK;
 #define NT_ISSUE(kt_, stage_)                                                          \
     do {                                                                               \
         const size_t ko_ = (size_t)(kt_) * P_BK;                                       \
@@ -213,21 +346,28 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
         constexpr int EP = 64 * 4 + 16;
         const int rr8 = lane >> 3, cc = (lane & 7) * 8;
         const int n = n0 + wn * 64 + cc, nc = min(n, N - 8);
+        // the eight passes (two 32-row halves x four) are one pipeline: the inputs of pass P + LNB_D - 1 are requested before pass P
+        // is computed (clamped addresses; invalid lanes never store), across the staging of the second half as well
+#ifndef MBX_LNB_DEPTH
+#define MBX_LNB_DEPTH 2
+#endif
+        constexpr int LNB_D = MBX_LNB_DEPTH;
+        const int mb0 = m0 + wm * 64;
+        float4 dy0[LNB_D], dy1[LNB_D], rc[LNB_D];
+        uint4 xh[LNB_D];
+#define LNB_LOAD(P_)                                                                            \
+        do {                                                                                    \
+            const size_t mo_ = (size_t)min(mb0 + (P_) * 8 + rr8, M - 1);                        \
+            rc[(P_) % LNB_D] = rowc[mo_];                                                       \
+            dy0[(P_) % LNB_D] = epi_load_f4<MBX_LD_LNB>(resid + mo_ * N + nc);                              \
+            dy1[(P_) % LNB_D] = epi_load_f4<MBX_LD_LNB>(resid + mo_ * N + nc + 4);                          \
+            xh[(P_) % LNB_D] = epi_load_u4<MBX_LD_LNB>(aux + mo_ * N + nc);                                 \
+        } while (0)
+#pragma unroll
+        for (int P = 0; P < LNB_D - 1; ++P) LNB_LOAD(P);
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
-            const int mb = m0 + wm * 64 + tm * 32;
-            // the inputs of pass p+1 are requested before pass p is computed (clamped addresses; invalid lanes never store)
-            float4 dy0[2], dy1[2], rc[2];
-            uint4 xh[2];
-#define LNB_LOAD(slot_, p_)                                                                         \
-            do {                                                                                    \
-                const size_t mo_ = (size_t)min(mb + (p_) * 8 + rr8, M - 1);                         \
-                rc[slot_] = rowc[mo_];                                                              \
-                dy0[slot_] = *reinterpret_cast<const float4*>(resid + mo_ * N + nc);                \
-                dy1[slot_] = *reinterpret_cast<const float4*>(resid + mo_ * N + nc + 4);            \
-                xh[slot_] = *reinterpret_cast<const uint4*>(aux + mo_ * N + nc);                    \
-            } while (0)
-            LNB_LOAD(0, 0);
+            const int mb = mb0 + tm * 32;
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -236,8 +376,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
                         make_float4(acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                if (p + 1 < 4) LNB_LOAD((p + 1) & 1, p + 1);
-                const int rl = p * 8 + rr8, m = mb + rl, sl = p & 1;
+                if (tm * 4 + p + LNB_D - 1 < 8) LNB_LOAD(tm * 4 + p + LNB_D - 1);
+                const int rl = p * 8 + rr8, m = mb + rl, sl = (tm * 4 + p) % LNB_D;
                 const float4 a0 = *reinterpret_cast<const float4*>(er + rl * EP + cc * 4);
                 const float4 a1 = *reinterpret_cast<const float4*>(er + rl * EP + cc * 4 + 16);
                 if (m < M && n < N) {
@@ -278,10 +418,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
         // RESID: all eight residual loads of this half are issued BEFORE the accumulators are staged, so their HBM latency
         // runs under the LDS round trip (clamped addresses, unconditional: out-of-range lanes never store)
         float4 rr[8];
-        if (EPI == MBX_EPI_RESID) {
+        if (EPI == MBX_EPI_RESID || EPI == MBX_EPI_RESID_LN) {
 #pragma unroll
             for (int p = 0; p < 8; ++p)
-                rr[p] = *reinterpret_cast<const float4*>(resid + (size_t)min(m0 + wm * 64 + p * 8 + erow0, M - 1) * N + min(n, N - 4));
+                rr[p] = epi_load_f4<MBX_LD_RES>(resid + (size_t)min(m0 + wm * 64 + p * 8 + erow0, M - 1) * N + min(n, N - 4));
         }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -305,7 +445,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                     store4<bf16_t>(out2_t + o, v);
-                } else if (EPI == MBX_EPI_RESID) {
+                } else if (EPI == MBX_EPI_RESID || EPI == MBX_EPI_RESID_LN) {
                     v[0] += rr[p].x; v[1] += rr[p].y; v[2] += rr[p].z; v[3] += rr[p].w;
                     epi_store16<MBX_ST_RES>(out_f + o, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
                 } else if (EPI == MBX_EPI_TANH) {
@@ -326,6 +466,30 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TSTAMP(2 + nk * 4);
 #undef TSTAMP
+    if constexpr (EPI == MBX_EPI_RESID_LN) {
+        // this wave's stores are in L2 (vmcnt(0) above); after the barrier, so are the workgroup's
+        __shared__ int s_last;
+        if (dbg & 32) return;      // diagnostics: no hand-shake, no tail (the residual GEMM in the row-block-granular order)
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) {
+            const unsigned xcc = mbx_xcc_id();
+            unsigned* c = ln.cnt + m0 / P_BM;
+            const unsigned old = __hip_atomic_fetch_add(c, 1u | (xcc << 8) | (xcc * xcc << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old & 0xffu) == (unsigned)(ntn - 1);
+            if (last) {
+                const unsigned sx = ((old >> 8) & 0xffu) + xcc, sxx = (old >> 16) + xcc * xcc;
+                if (sx != (unsigned)ntn * xcc || sxx != (unsigned)ntn * xcc * xcc) __builtin_trap();   // a contributor ran on another XCD
+                __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_last = last;
+        }
+        __builtin_amdgcn_s_barrier();
+        if (!s_last || (dbg & 16)) return;      // dbg 16: hand-shake without the tail
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (N == 512) ln_tail_block<2>(out_f, out_t, ln, m0, M, N, wave, lane);
+        else if (N == 256) ln_tail_block<1>(out_f, out_t, ln, m0, M, N, wave, lane);
+        else ln_tail_block<4>(out_f, out_t, ln, m0, M, N, wave, lane);
+    }
 }
 
 // ================================================================================================
@@ -511,13 +675,13 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
         const bf16_t* auxc = aux + min(n, N - 8);
         uint4 ua[2][4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ua[0][p] = *reinterpret_cast<const uint4*>(auxc + (size_t)min(row_base + p * 8 + rr, M - 1) * N);
+        for (int p = 0; p < 4; ++p) ua[0][p] = epi_load_u4<MBX_LD_DG>(auxc + (size_t)min(row_base + p * 8 + rr, M - 1) * N);
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
             if (tm + 1 < 4) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    ua[(tm + 1) & 1][p] = *reinterpret_cast<const uint4*>(auxc + (size_t)min(row_base + (tm + 1) * 32 + p * 8 + rr, M - 1) * N);
+                    ua[(tm + 1) & 1][p] = epi_load_u4<MBX_LD_DG>(auxc + (size_t)min(row_base + (tm + 1) * 32 + p * 8 + rr, M - 1) * N);
             }
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
@@ -947,7 +1111,7 @@ int mbx_launch_gemm_nt_pipe(const void* a, const void* w, const float* bias, int
         if (set_lds_attr(gemm_nt_pipe_kernel<E>, shm, "gemm_nt_pipe")) return 1;                                      \
         hipLaunchKernelGGL((gemm_nt_pipe_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w, bias,   \
                            (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn,           \
-                           (const float4*)nullptr, (const float*)nullptr MBX_NTP_DIAG_ARGS);                          \
+                           (const float4*)nullptr, (const float*)nullptr, NtLnTail{} MBX_NTP_DIAG_ARGS);              \
         break;
     switch (epi) {
         MBX_NTP_CASE(MBX_EPI_STORE)
@@ -986,12 +1150,54 @@ extern "C" int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat,
     if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_LNBWD>, shm, "gemm_nt_lnbwd")) return 1;
     hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_LNBWD>), dim3((unsigned)ntn * ntm), dim3(512), shm, s, (const bf16_t*)a, (const bf16_t*)w,
                        (const float*)nullptr, (bf16_t*)dx_t, (bf16_t*)nullptr, dx, dres, (const bf16_t*)xhat, M, N, K, ntn,
-                       reinterpret_cast<const float4*>(rowc), extra
+                       reinterpret_cast<const float4*>(rowc), extra, NtLnTail{}
 #ifdef MBX_DIAG
                        , dbg, trace
 #endif
                        );
     MBX_LAUNCH_CHECK("gemm_nt_lnbwd");
+    return 0;
+}
+
+// y = resid + a . Wt + b  and, from the same launch,  xn = LayerNorm(y) (gamma / beta, or plain normalisation when both are NULL),
+// mean, rstd: the residual GEMM (DSTformer.py:241-249) followed by the next sub-layer's norm.  N = 256, 512 or 1024 (a full row).
+extern "C" size_t mbx_gemm_nt_resid_ln_ws(int M) { return (size_t)((M + P_BM - 1) / P_BM) * sizeof(unsigned); }
+extern "C" int mbx_gemm_nt_resid_ln(const void* a, const void* w, const float* bias, const float* resid, float* y, const float* gamma,
+                                    const float* beta, float eps, void* xn, float* mean, float* rstd, int M, int N, int K, void* ws,
+                                    void* stream) {
+    MBX_CHECK_ARG(a && w && resid && y && xn && mean && rstd && ws, "gemm_nt_resid_ln: null pointer");
+    MBX_CHECK_ARG((gamma && beta) || (!gamma && !beta), "gemm_nt_resid_ln: gamma and beta come together (both NULL = plain normalisation)");
+    MBX_CHECK_ARG(M > 0 && (N == 256 || N == 512 || N == 1024) && K > 0 && K % 64 == 0,
+                  "gemm_nt_resid_ln: bad shape M=%d N=%d K=%d (N in {256, 512, 1024}, K %% 64)", M, N, K);
+    MBX_CHECK_ARG(y != resid, "gemm_nt_resid_ln: y must not alias resid");
+    const int ntn = N / P_BN, ntm = (M + P_BM - 1) / P_BM;
+    const size_t shm = P_NSTAGE * P_STAGE;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, mbx_gemm_nt_resid_ln_ws(M), s) != hipSuccess) return mbx_set_error("gemm_nt_resid_ln: counter reset failed");
+#ifdef MBX_DIAG
+    static const int dbg = mbx_env_int("MBX_DBG", 0);
+#endif
+    if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_RESID_LN>, shm, "gemm_nt_resid_ln")) return 1;
+    const NtLnTail ln{mean, rstd, gamma, beta, (unsigned*)ws, eps};
+    hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_RESID_LN>), dim3((unsigned)(8 * ntn * ((ntm + 7) / 8))), dim3(512), shm, s, (const bf16_t*)a,
+                       (const bf16_t*)w, bias, (bf16_t*)xn, (bf16_t*)nullptr, y, resid, (const bf16_t*)nullptr, M, N, K, ntn,
+                       (const float4*)nullptr, (const float*)nullptr, ln
+#ifdef MBX_DIAG
+                       , dbg, (long long*)nullptr
+#endif
+                       );
+    MBX_LAUNCH_CHECK("gemm_nt_resid_ln");
+    return 0;
+}
+// XCC id of every workgroup of a launch of `nblocks` one-wave workgroups: the host checks that workgroups with equal blockIdx & 7
+// share an XCD before it enables mbx_gemm_nt_resid_ln (hip_ops.can_fuse_resid_ln)
+__global__ void xcc_probe_kernel(int* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)mbx_xcc_id();
+}
+extern "C" int mbx_xcc_probe(int* out, int nblocks, void* stream) {
+    MBX_CHECK_ARG(out && nblocks > 0, "xcc_probe: bad arguments");
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, out);
+    MBX_LAUNCH_CHECK("xcc_probe");
     return 0;
 }
 

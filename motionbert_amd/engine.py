@@ -152,6 +152,9 @@ class Engine:
                      bool(getattr(ops, 'can_fold', lambda *_: False)(tdtype, cfg)))
         self.Bf: Dict[str, torch.Tensor] = {}
         self.Rs: Dict[str, torch.Tensor] = {}
+        # residual GEMM + the next LayerNorm forward in one launch (round 3, bf16 path; include/mbx.h): decided at the first forward
+        # (the provider checks the device's workgroup -> XCD rule once).  Opt-in with MBX_RESID_LN=1: measured time-neutral at 64 clips
+        self.resid_ln = None
 
     def _streams(self):
         """(main, side) streams for the dual-stream schedule, or (None, None)."""
@@ -256,6 +259,8 @@ class Engine:
             B = 2 * B
         M, C = B * T * J, cfg.C
         self.B, self.Tlen, self.M = B, T, M
+        if self.resid_ln is None:
+            self.resid_ln = (not self.x3) and bool(getattr(ops, 'can_fuse_resid_ln', lambda *_: False)(self.T, cfg.C, x.device))
         self.prepare_weights(need_grad)
         h = self._f(M, C)
         if tta_perm is not None:
@@ -340,19 +345,40 @@ class Engine:
         return out, saved
 
     def _block_fwd(self, x, pre, kind, need_grad, ln=None):
+        """`ln` = (xn, mean, rstd) of x when its producer already normalised it: the fusion kernel of the previous level for the
+        first sub-layer, the residual GEMM of the previous sub-layer for the others (`gemm_nt_resid_ln`)."""
         svs = []
-        for sub, (typ, norm, mod, mode) in enumerate(ORDER[kind]):
+        order = ORDER[kind]
+        for sub, (typ, norm, mod, mode) in enumerate(order):
+            nxt = order[sub + 1][1] if sub + 1 < len(order) else None      # the norm that reads this sub-layer's output
             if typ == 'attn':
-                x, sv = self._attn_fwd(x, pre, norm, mod, mode, need_grad, sub, ln if sub == 0 else None)
+                x, sv, ln = self._attn_fwd(x, pre, norm, mod, mode, need_grad, sub, ln, nxt)
             else:
-                x, sv = self._mlp_fwd(x, pre, norm, mod, need_grad, sub)
+                x, sv, ln = self._mlp_fwd(x, pre, norm, mod, need_grad, sub, ln, nxt)
             svs.append(sv)
         return x, svs
 
-    def _attn_fwd(self, x, pre, norm, attn, mode, need_grad, sub=0, ln=None):
+    def _resid_gemm(self, a, lin, x, dm, pre, nxt):
+        """y = x + a . W^T + b (fp32 residual stream).  When the output feeds the LayerNorm `nxt` of the same Block and nothing
+        touches y in between (no branch dropout), the same launch also writes that LayerNorm's output: returns (y, ln or None)."""
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C = self.M, cfg.C
-        if ln is not None:            # LayerNorm(x) came with x from the fusion kernel of the previous level
+        y = self._f(M, C)
+        drop = dm is not None and (dm[0] > 0 or dm[3] > 0)
+        if nxt is not None and not drop and self.resid_ln:
+            xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+            g, b = (None, None) if self.fold else (P[f'{pre}.{nxt}.weight'], P[f'{pre}.{nxt}.bias'])
+            ops.gemm_nt_resid_ln(a, self.Wn[lin], P[lin + '.bias'], x, y, g, b, cfg.eps, xn, mean, rstd)
+            return y, (xn, mean, rstd)
+        ops.gemm_nt(a, self.Wn[lin], P[lin + '.bias'], EPI_RESID, resid=x, out_f=y)
+        if drop:      # proj_drop / MLP drop + DropPath on the branch (DSTformer.py:84,148-149,241-242)
+            ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])
+        return y, None
+
+    def _attn_fwd(self, x, pre, norm, attn, mode, need_grad, sub=0, ln=None, nxt=None):
+        cfg, ops, P = self.cfg, self.ops, self.P
+        M, C = self.M, cfg.C
+        if ln is not None:            # LayerNorm(x) came with x from its producer
             xn, mean, rstd = ln
         else:
             xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
@@ -370,24 +396,24 @@ class Engine:
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode, drop=(dm[5], dm[6]))
         else:
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
-        y = self._f(M, C)
-        ops.gemm_nt(self._mm(o), self.Wn[f'{pre}.{attn}.proj'], P[f'{pre}.{attn}.proj.bias'], EPI_RESID, resid=x, out_f=y)
-        if dm is not None and (dm[0] > 0 or dm[3] > 0):      # proj_drop + DropPath on the branch (DSTformer.py:148-149,241)
-            ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])
+        y, ln_y = self._resid_gemm(self._mm(o), f'{pre}.{attn}.proj', x, dm, pre, nxt)
         if self.fold:      # backward needs xhat and rstd only: the fp32 sub-layer input is not kept
             sv = dict(x=None, mean=None, rstd=rstd, xn=xn, qkv=qkv, o=o, lse=lse, dm=dm) if need_grad else None
         else:
             sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, qkv=qkv, o=o, lse=lse, dm=dm) if need_grad else None
-        return y, sv
+        return y, sv, ln_y
 
-    def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1):
+    def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1, ln=None, nxt=None):
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C = self.M, cfg.C
-        xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
-        if self.fold:
-            ops.layernorm_fwd(x, None, None, cfg.eps, xn, mean, rstd)
+        if ln is not None:            # LayerNorm(x) came with x from the residual GEMM of the previous sub-layer
+            xn, mean, rstd = ln
         else:
-            ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
+            xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+            if self.fold:
+                ops.layernorm_fwd(x, None, None, cfg.eps, xn, mean, rstd)
+            else:
+                ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
         xn = self._mm(xn)
         u, g = (self._t(M, cfg.hidden) if need_grad else None), self._t(M, cfg.hidden)   # u only feeds GELU' in backward
         ops.gemm_nt(xn, self.Wn[f'{pre}.{mlp}.fc1'], self.Bf[f'{pre}.{mlp}.fc1'] if self.fold else P[f'{pre}.{mlp}.fc1.bias'],
@@ -396,15 +422,12 @@ class Engine:
         if dm is not None and dm[0] > 0:                      # MLP drop after the activation (DSTformer.py:82)
             ops.dropout(g, g, dm[0], dm[2])
         g = self._mm(g)
-        y = self._f(M, C)
-        ops.gemm_nt(g, self.Wn[f'{pre}.{mlp}.fc2'], P[f'{pre}.{mlp}.fc2.bias'], EPI_RESID, resid=x, out_f=y)
-        if dm is not None and (dm[0] > 0 or dm[3] > 0):      # MLP drop after fc2 + DropPath (DSTformer.py:84,242)
-            ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])
+        y, ln_y = self._resid_gemm(g, f'{pre}.{mlp}.fc2', x, dm, pre, nxt)
         if self.fold:
             sv = dict(x=None, mean=None, rstd=rstd, xn=xn, u=u, g=None if self.recompute else g, dm=dm) if need_grad else None
         else:
             sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, u=u, g=None if self.recompute else g, dm=dm) if need_grad else None
-        return y, sv
+        return y, sv, ln_y
 
     # ----------------------------------------------------------------- backward
     def backward(self, saved, dout: torch.Tensor, grads: Dict[str, torch.Tensor], want_dx: bool, on_ready=None):

@@ -194,6 +194,25 @@ class MockOps:
         else:
             raise ValueError(epi)
 
+    fuse_resid_ln = True      # tests switch it off to exercise the unfused sequencing
+
+    def can_fuse_resid_ln(self, tdtype, N, device=None):
+        return bool(self.fuse_resid_ln)
+
+    def gemm_nt_resid_ln(self, a_t, w_t, bias, resid, y, gamma, beta, eps, xn, mean, rstd):
+        """y = resid + a . w^T + bias;  xn, mean, rstd = LayerNorm forward of y (gamma = beta = None: plain normalisation)."""
+        self._log('gemm_nt.resid_ln')
+        acc = a_t.float() @ w_t.float().t()
+        if bias is not None:
+            acc = acc + bias
+        y.copy_(resid + acc)
+        mu = y.mean(-1)
+        rs = torch.rsqrt(((y - mu[:, None]) ** 2).mean(-1) + eps)
+        mean.copy_(mu)
+        rstd.copy_(rs)
+        xhat = (y - mu[:, None]) * rs[:, None]
+        xn.copy_((xhat if gamma is None else xhat * gamma + beta).to(xn.dtype))
+
     def gelu_fwd(self, u, g):
         self._log('gelu_fwd')
         g.copy_(F.gelu(u.float()).to(g.dtype))

@@ -1,5 +1,5 @@
 """Per-kernel register / LDS usage of the built libmbx.so (from the code objects' metadata notes).
-    python tools/kernel_regs.py [pattern]"""
+    python tools/kernel_regs.py [pattern] [--lib path]"""
 import os, re, shutil, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,10 +7,13 @@ LLVM = '/opt/rocm/lib/llvm/bin'
 
 
 def main():
+    src = os.path.join(ROOT, 'motionbert_amd', 'libmbx.so')
+    if '--lib' in sys.argv:
+        k = sys.argv.index('--lib'); src = sys.argv[k + 1]; del sys.argv[k:k + 2]
     pat = sys.argv[1] if len(sys.argv) > 1 else ''
     tmp = tempfile.mkdtemp()
     lib = os.path.join(tmp, 'libmbx.so')
-    shutil.copy(os.path.join(ROOT, 'motionbert_amd', 'libmbx.so'), lib)
+    shutil.copy(src, lib)
     subprocess.run([f'{LLVM}/llvm-objdump', '--offloading', lib], check=True, capture_output=True, cwd=tmp)
     rows = []
     for f in sorted(os.listdir(tmp)):
