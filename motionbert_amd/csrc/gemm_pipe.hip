@@ -308,9 +308,6 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
             NT_ISSUE(kt + 2, st2);
         }
         TSTAMP(3 + kt * 4);
-            }
-        }
-#endif
         const char* sA = smem + stage * P_STAGE;
         const char* sW = sA + P_A_BYTES;
         if (!(dbg & 1))
