@@ -258,15 +258,22 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) ==
     char* vt = kt + KBYTES;
     const size_t rstride = (size_t)P.tstep * C3;
     const T* base = qkv + P.tok0 * C3 + (size_t)P.h * HD;
-    fill_two<T, HD>(kt, base + C, rstride, vt, base + 2 * C, rstride, KSTR, P.L, KP, gtid, gsize);
-    __syncthreads();
-
     const int nfr = (P.L + 31) / 32;
-    const float c2 = scale * 1.44269504088896341f;
     // L <= 256 (check_attn_args): at most eight 32-query blocks -- one per wave of a shared workgroup, one in all for a
     // wave-private problem
     const int qb = SHARED ? wave : 0;
     const int q = qb * 32 + (lane & 31);
+    // this lane's query row is requested BEFORE the K / V fill (round 3): one memory round trip for the prologue instead of two
+#ifndef MBX_ATTN_Q_EARLY
+#define MBX_ATTN_Q_EARLY 1
+#endif
+    BReg<T, HD> qreg;
+    if (MBX_ATTN_Q_EARLY && qb < nfr)
+        qreg.load(qkv + (P.tok0 + (size_t)min(q, P.L - 1) * P.tstep) * C3 + (size_t)P.h * HD, g, pvalid && q < P.L);
+    fill_two<T, HD>(kt, base + C, rstride, vt, base + 2 * C, rstride, KSTR, P.L, KP, gtid, gsize);
+    __syncthreads();
+
+    const float c2 = scale * 1.44269504088896341f;
     f32x16_t oacc[HD / 32];
 #pragma unroll
     for (int df = 0; df < HD / 32; ++df)
@@ -276,8 +283,7 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) ==
     if (qb < nfr) {
         const bool qvalid = pvalid && q < P.L;
         const size_t tok = P.tok0 + (size_t)min(q, P.L - 1) * P.tstep;
-        BReg<T, HD> qreg;
-        qreg.load(qkv + tok * C3 + (size_t)P.h * HD, g, qvalid);
+        if (!MBX_ATTN_Q_EARLY) qreg.load(qkv + tok * C3 + (size_t)P.h * HD, g, qvalid);
         // softmax in base 2: p = 2^(s*c2 - m2) with c2 = scale*log2(e) -- one fma + one v_exp_f32 per score; the max is
         // taken over the raw scores (scale > 0) and only the tail fragment masks keys past L
         float m2 = -INFINITY;
@@ -590,32 +596,100 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     const T* dobase = d_o + P.tok0 * C + (size_t)P.h * HD;
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
-    fill_two<T, HD>(qt, qbase, rstride, kt, qbase + C, rstride, RSTR, P.L, KP, lane, 64);
-    fill_two<T, HD>(vt, qbase + 2 * C, rstride, dot_, dobase, ostride, RSTR, P.L, KP, lane, 64);
+#ifndef MBX_ATTN_SMALL_EARLY
+#define MBX_ATTN_SMALL_EARLY 1
+#endif
+    constexpr bool EARLY = MBX_ATTN_SMALL_EARLY && sizeof(T) == 2;
     uint4 vec_reg = make_uint4(0u, 0u, 0u, 0u);      // this lane's entry of the row-dot vectors (3 hd / 4 <= 48 entries), parked in registers
-    if (stats && lane < 3 * HD / 4) {
-        const int j = lane / (HD / 4), d = (lane % (HD / 4)) * 4;
-        const float4 r = *reinterpret_cast<const float4*>(st_rsum + j * C + P.h * HD + d);
-        const float4 b = *reinterpret_cast<const float4*>(st_bias + j * C + P.h * HD + d);
-        vec_reg = make_uint4(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w), pack_bf2(-b.x, -b.y), pack_bf2(-b.z, -b.w));
-    }
-    {   // per-row statistics: lse and delta = sum_d dO * O (one row per lane, all loads in flight together)
-        const int q = lane;
-        if (q < KP) {
-            float l = 0.f, dl = 0.f;
-            if (q < P.L) {
-                l = lse[(P.tok0 + (size_t)q * P.tstep) * H + P.h];
-                const T* a = dobase + (size_t)q * ostride;
-                const T* b = obase + (size_t)q * ostride;
-                float x[HD / 4][4], y[HD / 4][4];
+    if constexpr (EARLY) {
+        // ONE memory round trip for the whole prologue: the statistics' operands (lse, this lane's row of O) and the chunks of all
+        // four tiles are requested before the first LDS store; delta = dO . O then takes dO from the tile (wave-private tiles, LDS
+        // operations of a wave execute in order).  Before: two fills and the statistics, three round trips in a row, on a kernel
+        // with eight waves per CU.
+        constexpr int CHB = HD / 8, NPT = KP * CHB / 64;      // 16-byte chunks per row; chunks per lane and tile (4 at hd = 64)
+        float l = 0.f;
+        uint4 orow[HD / 8];
 #pragma unroll
-                for (int d = 0; d < HD / 4; ++d) { load4<T>(a + 4 * d, x[d]); load4<T>(b + 4 * d, y[d]); }
+        for (int d = 0; d < HD / 8; ++d) orow[d] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < P.L) {
+            l = lse[(P.tok0 + (size_t)lane * P.tstep) * H + P.h];
+            const T* b = obase + (size_t)lane * ostride;
 #pragma unroll
-                for (int d = 0; d < HD / 4; ++d)
-                    dl = fmaf(x[d][0], y[d][0], fmaf(x[d][1], y[d][1], fmaf(x[d][2], y[d][2], fmaf(x[d][3], y[d][3], dl))));
+            for (int d = 0; d < HD / 8; ++d) orow[d] = *reinterpret_cast<const uint4*>(b + 8 * d);
+        }
+        uint4 tq[NPT], tk[NPT], tv[NPT], td[NPT];
+#pragma unroll
+        for (int c = 0; c < NPT; ++c) {
+            const int idx = lane + c * 64, row = idx / CHB, ch = idx % CHB;
+            tq[c] = tk[c] = tv[c] = td[c] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < P.L) {
+                const T* r3 = qbase + (size_t)row * rstride + ch * 8;
+                tq[c] = *reinterpret_cast<const uint4*>(r3);
+                tk[c] = *reinterpret_cast<const uint4*>(r3 + C);
+                tv[c] = *reinterpret_cast<const uint4*>(r3 + 2 * C);
+                td[c] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * ostride + ch * 8);
             }
-            lse_s[q] = l;
-            del_s[q] = dl;
+        }
+        if (stats && lane < 3 * HD / 4) {
+            const int j = lane / (HD / 4), d = (lane % (HD / 4)) * 4;
+            const float4 r = *reinterpret_cast<const float4*>(st_rsum + j * C + P.h * HD + d);
+            const float4 b = *reinterpret_cast<const float4*>(st_bias + j * C + P.h * HD + d);
+            vec_reg = make_uint4(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w), pack_bf2(-b.x, -b.y), pack_bf2(-b.z, -b.w));
+        }
+#pragma unroll
+        for (int c = 0; c < NPT; ++c) {
+            const int idx = lane + c * 64, off = (idx / CHB) * RSTR + (idx % CHB) * 16;
+            *reinterpret_cast<uint4*>(qt + off) = tq[c];
+            *reinterpret_cast<uint4*>(kt + off) = tk[c];
+            *reinterpret_cast<uint4*>(vt + off) = tv[c];
+            *reinterpret_cast<uint4*>(dot_ + off) = td[c];
+        }
+        if (lane < KP) {
+            float dl = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD / 8; ++d) {
+                const uint4 a = *reinterpret_cast<const uint4*>(dot_ + (size_t)lane * RSTR + d * 16);
+                const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {orow[d].x, orow[d].y, orow[d].z, orow[d].w};
+                float x[8], y[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[2 * e] = __uint_as_float(aw[e] << 16); x[2 * e + 1] = __uint_as_float(aw[e] & 0xffff0000u);
+                    y[2 * e] = __uint_as_float(bw[e] << 16); y[2 * e + 1] = __uint_as_float(bw[e] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int h4 = 0; h4 < 8; h4 += 4)      // the summation order of the separate-loads path below
+                    dl = fmaf(x[h4], y[h4], fmaf(x[h4 + 1], y[h4 + 1], fmaf(x[h4 + 2], y[h4 + 2], fmaf(x[h4 + 3], y[h4 + 3], dl))));
+            }
+            lse_s[lane] = l;
+            del_s[lane] = dl;
+        }
+    } else {
+        fill_two<T, HD>(qt, qbase, rstride, kt, qbase + C, rstride, RSTR, P.L, KP, lane, 64);
+        fill_two<T, HD>(vt, qbase + 2 * C, rstride, dot_, dobase, ostride, RSTR, P.L, KP, lane, 64);
+        if (stats && lane < 3 * HD / 4) {
+            const int j = lane / (HD / 4), d = (lane % (HD / 4)) * 4;
+            const float4 r = *reinterpret_cast<const float4*>(st_rsum + j * C + P.h * HD + d);
+            const float4 b = *reinterpret_cast<const float4*>(st_bias + j * C + P.h * HD + d);
+            vec_reg = make_uint4(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w), pack_bf2(-b.x, -b.y), pack_bf2(-b.z, -b.w));
+        }
+        {   // per-row statistics: lse and delta = sum_d dO * O (one row per lane, all loads in flight together)
+            const int q = lane;
+            if (q < KP) {
+                float l = 0.f, dl = 0.f;
+                if (q < P.L) {
+                    l = lse[(P.tok0 + (size_t)q * P.tstep) * H + P.h];
+                    const T* a = dobase + (size_t)q * ostride;
+                    const T* b = obase + (size_t)q * ostride;
+                    float x[HD / 4][4], y[HD / 4][4];
+#pragma unroll
+                    for (int d = 0; d < HD / 4; ++d) { load4<T>(a + 4 * d, x[d]); load4<T>(b + 4 * d, y[d]); }
+#pragma unroll
+                    for (int d = 0; d < HD / 4; ++d)
+                        dl = fmaf(x[d][0], y[d][0], fmaf(x[d][1], y[d][1], fmaf(x[d][2], y[d][2], fmaf(x[d][3], y[d][3], dl))));
+                }
+                lse_s[q] = l;
+                del_s[q] = dl;
+            }
         }
     }
     __syncthreads();
@@ -755,6 +829,12 @@ __device__ __forceinline__ void mma_rows_ldsb(const char* tile, int stride, int 
     }
 }
 
+struct Raw4b {     // four bf16 in a uint2 -> fp32
+    static __device__ __forceinline__ void unpack(const uint2& r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    }
+};
 template <int HD>
 __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                  const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
@@ -781,6 +861,27 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
     if (st_part) fill_stat_vec<HD>(vec, st_rsum, st_bias, C, P.h, tid, 1024);
 
+    // ---- the loads of the per-query statistics (dO . O, lse: four lanes per row, KP <= 256 rows = one pass of the 1024 threads) go
+    // out FIRST, so that their latency runs under the tile fill instead of after it (MBX_ATTN_STAT_EARLY=0: the old order) ----
+#ifndef MBX_ATTN_STAT_EARLY
+#define MBX_ATTN_STAT_EARLY 1
+#endif
+    const int sr = tid >> 2, spart = tid & 3;
+    uint2 sx[HD / 16], sy[HD / 16];
+    float sl = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD / 16; ++d) { sx[d] = make_uint2(0u, 0u); sy[d] = make_uint2(0u, 0u); }
+#define ATTN_STAT_LOAD()                                                                                   \
+    if (sr < P.L) {                                                                                        \
+        const T* a_ = dobase + (size_t)sr * ostride + spart * (HD / 4);                                    \
+        const T* b_ = obase + (size_t)sr * ostride + spart * (HD / 4);                                     \
+        _Pragma("unroll") for (int d = 0; d < HD / 16; ++d) {                                              \
+            sx[d] = *reinterpret_cast<const uint2*>(a_ + 4 * d);                                           \
+            sy[d] = *reinterpret_cast<const uint2*>(b_ + 4 * d);                                           \
+        }                                                                                                  \
+        sl = lse[(P.tok0 + (size_t)sr * P.tstep) * H + P.h];                                               \
+    }
+    if (MBX_ATTN_STAT_EARLY) { ATTN_STAT_LOAD(); }
     // ---- stage the four tiles: 16-byte chunks, all loads of a pass in flight before the first LDS store ----
     for (int i0 = tid; i0 < KP * CH; i0 += 2048) {
         uint4 v[2][4];
@@ -810,25 +911,21 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
         }
     }
     // ---- per-query statistics: four lanes per row, each HD/4 of the d range, quad-reduced on the VALU ----
-    for (int r = tid >> 2; r < KP; r += 256) {
-        const int part = tid & 3;
-        float dl = 0.f, l = 0.f;
-        if (r < P.L) {
-            const T* a = dobase + (size_t)r * ostride + part * (HD / 4);
-            const T* b = obase + (size_t)r * ostride + part * (HD / 4);
-            float x[HD / 16][4], y[HD / 16][4];
+    if (!MBX_ATTN_STAT_EARLY) { ATTN_STAT_LOAD(); }
+#undef ATTN_STAT_LOAD
+    if (sr < KP) {
+        float dl = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD / 16; ++d) { load4<T>(a + 4 * d, x[d]); load4<T>(b + 4 * d, y[d]); }
-#pragma unroll
-            for (int d = 0; d < HD / 16; ++d)
-                dl = fmaf(x[d][0], y[d][0], fmaf(x[d][1], y[d][1], fmaf(x[d][2], y[d][2], fmaf(x[d][3], y[d][3], dl))));
-            l = lse[(P.tok0 + (size_t)r * P.tstep) * H + P.h];
+        for (int d = 0; d < HD / 16; ++d) {
+            float x[4], y[4];
+            Raw4b::unpack(sx[d], x); Raw4b::unpack(sy[d], y);
+            dl = fmaf(x[0], y[0], fmaf(x[1], y[1], fmaf(x[2], y[2], fmaf(x[3], y[3], dl))));
         }
         dl += dpp_mov<0xB1>(dl, dl);    // quad_perm [1,0,3,2]
         dl += dpp_mov<0x4E>(dl, dl);    // quad_perm [2,3,0,1]
-        if (part == 0) {
-            lse_s[r] = l * 1.44269504088896341f;   // base-2 units: p = 2^(s*c2 - lse2)
-            del_s[r] = dl;
+        if (spart == 0) {
+            lse_s[sr] = sl * 1.44269504088896341f;   // base-2 units: p = 2^(s*c2 - lse2)
+            del_s[sr] = dl;
         }
     }
     __syncthreads();
