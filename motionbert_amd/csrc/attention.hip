@@ -162,11 +162,12 @@ template <> struct MmaCols<float> {
 // Two row-major tiles at once: dstX[row][0..HD) = srcX[row * rstrideX + 0..HD) for row < L, zero for
 // L <= row < KP.  All global loads of both tiles are issued before the first LDS store (the rows are
 // kilobytes apart, so each load is a separate HBM/L2 round trip: they must overlap, not serialize).
-template <typename T, int HD>
+// NPT = chunks per thread and tile: CH covers KP <= gsize; callers with KP <= gsize / 2 (32 rows per 64 lanes, <= 256 rows per 512
+// threads) pass CH / 2 and keep half of the staging registers
+template <typename T, int HD, int NPT = HD / AT<T>::EPC>
 __device__ __forceinline__ void fill_two(char* dst0, const T* src0, size_t rs0, char* dst1, const T* src1, size_t rs1, int stride,
-                                         int L, int KP, int gtid, int gsize, uint4 (&v0)[HD / AT<T>::EPC], uint4 (&v1)[HD / AT<T>::EPC]) {
-    constexpr int CH = HD / AT<T>::EPC;   // 16-byte chunks per row; gsize * CH >= KP * CH for both launch shapes
-    constexpr int NPT = CH;               // chunks per thread and tile (KP <= gsize)
+                                         int L, int KP, int gtid, int gsize, uint4 (&v0)[NPT], uint4 (&v1)[NPT]) {
+    constexpr int CH = HD / AT<T>::EPC;   // 16-byte chunks per row
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int idx = gtid + i * gsize, row = idx / CH, ch = idx % CH;
@@ -186,11 +187,11 @@ __device__ __forceinline__ void fill_two(char* dst0, const T* src0, size_t rs0, 
         }
     }
 }
-template <typename T, int HD>
+template <typename T, int HD, int NPT = HD / AT<T>::EPC>
 __device__ __forceinline__ void fill_two(char* dst0, const T* src0, size_t rs0, char* dst1, const T* src1, size_t rs1, int stride,
                                          int L, int KP, int gtid, int gsize) {
-    uint4 v0[HD / AT<T>::EPC], v1[HD / AT<T>::EPC];
-    fill_two<T, HD>(dst0, src0, rs0, dst1, src1, rs1, stride, L, KP, gtid, gsize, v0, v1);
+    uint4 v0[NPT], v1[NPT];
+    fill_two<T, HD, NPT>(dst0, src0, rs0, dst1, src1, rs1, stride, L, KP, gtid, gsize, v0, v1);
 }
 // store an accumulator pair/quad set: lane owns sequence element `row`, registers own d
 template <typename T, int HD>
@@ -239,7 +240,7 @@ template <typename T> __host__ __device__ constexpr int rm_stride(int HD) { retu
 // is at most 8 fragments, but keeping only one fragment of scores live keeps the wave at ~100 VGPRs)
 // ================================================================================================
 template <typename T, int HD, bool SHARED, bool DROP = false>
-__global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) == 2 && !DROP) ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+__global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (sizeof(T) == 2 && !DROP) ? 4 : 1) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
                                                        int Tn, int J, int H, float scale, int mode, int nprob, int KP, MbxDrop dr) {
     constexpr bool IS_BF = sizeof(T) == 2;
     constexpr int KSTR = rm_stride<T>(HD);
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) ==
     BReg<T, HD> qreg;
     if (MBX_ATTN_Q_EARLY && qb < nfr)
         qreg.load(qkv + (P.tok0 + (size_t)min(q, P.L - 1) * P.tstep) * C3 + (size_t)P.h * HD, g, pvalid && q < P.L);
-    fill_two<T, HD>(kt, base + C, rstride, vt, base + 2 * C, rstride, KSTR, P.L, KP, gtid, gsize);
+    fill_two<T, HD, HD / AT<T>::EPC / 2>(kt, base + C, rstride, vt, base + 2 * C, rstride, KSTR, P.L, KP, gtid, gsize);
     __syncthreads();
 
     const float c2 = scale * 1.44269504088896341f;
@@ -664,8 +665,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
             del_s[lane] = dl;
         }
     } else {
-        fill_two<T, HD>(qt, qbase, rstride, kt, qbase + C, rstride, RSTR, P.L, KP, lane, 64);
-        fill_two<T, HD>(vt, qbase + 2 * C, rstride, dot_, dobase, ostride, RSTR, P.L, KP, lane, 64);
+        fill_two<T, HD, HD / AT<T>::EPC / 2>(qt, qbase, rstride, kt, qbase + C, rstride, RSTR, P.L, KP, lane, 64);
+        fill_two<T, HD, HD / AT<T>::EPC / 2>(vt, qbase + 2 * C, rstride, dot_, dobase, ostride, RSTR, P.L, KP, lane, 64);
         if (stats && lane < 3 * HD / 4) {
             const int j = lane / (HD / 4), d = (lane % (HD / 4)) * 4;
             const float4 r = *reinterpret_cast<const float4*>(st_rsum + j * C + P.h * HD + d);
