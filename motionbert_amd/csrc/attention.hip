@@ -603,21 +603,11 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
     constexpr bool EARLY = MBX_ATTN_SMALL_EARLY && sizeof(T) == 2;
     uint4 vec_reg = make_uint4(0u, 0u, 0u, 0u);      // this lane's entry of the row-dot vectors (3 hd / 4 <= 48 entries), parked in registers
     if constexpr (EARLY) {
-        // ONE memory round trip for the whole prologue: the statistics' operands (lse, this lane's row of O) and the chunks of all
-        // four tiles are requested before the first LDS store; delta = dO . O then takes dO from the tile (wave-private tiles, LDS
-        // operations of a wave execute in order).  Before: two fills and the statistics, three round trips in a row, on a kernel
-        // with eight waves per CU.
+        // ONE memory round trip for the whole prologue: lse and the chunks of all four tiles are requested before the first LDS
+        // store.  Before: two fills and the statistics, three round trips in a row, on a kernel with eight waves per CU.
         constexpr int CHB = HD / 8, NPT = KP * CHB / 64;      // 16-byte chunks per row; chunks per lane and tile (4 at hd = 64)
         float l = 0.f;
-        uint4 orow[HD / 8];
-#pragma unroll
-        for (int d = 0; d < HD / 8; ++d) orow[d] = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < P.L) {
-            l = lse[(P.tok0 + (size_t)lane * P.tstep) * H + P.h];
-            const T* b = obase + (size_t)lane * ostride;
-#pragma unroll
-            for (int d = 0; d < HD / 8; ++d) orow[d] = *reinterpret_cast<const uint4*>(b + 8 * d);
-        }
+        if (lane < P.L) l = lse[(P.tok0 + (size_t)lane * P.tstep) * H + P.h];
         uint4 tq[NPT], tk[NPT], tv[NPT], td[NPT];
 #pragma unroll
         for (int c = 0; c < NPT; ++c) {
@@ -645,25 +635,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
             *reinterpret_cast<uint4*>(vt + off) = tv[c];
             *reinterpret_cast<uint4*>(dot_ + off) = td[c];
         }
-        if (lane < KP) {
-            float dl = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD / 8; ++d) {
-                const uint4 a = *reinterpret_cast<const uint4*>(dot_ + (size_t)lane * RSTR + d * 16);
-                const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {orow[d].x, orow[d].y, orow[d].z, orow[d].w};
-                float x[8], y[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    x[2 * e] = __uint_as_float(aw[e] << 16); x[2 * e + 1] = __uint_as_float(aw[e] & 0xffff0000u);
-                    y[2 * e] = __uint_as_float(bw[e] << 16); y[2 * e + 1] = __uint_as_float(bw[e] & 0xffff0000u);
-                }
-#pragma unroll
-                for (int h4 = 0; h4 < 8; h4 += 4)      // the summation order of the separate-loads path below
-                    dl = fmaf(x[h4], y[h4], fmaf(x[h4 + 1], y[h4 + 1], fmaf(x[h4 + 2], y[h4 + 2], fmaf(x[h4 + 3], y[h4 + 3], dl))));
-            }
-            lse_s[lane] = l;
-            del_s[lane] = dl;
-        }
+        if (lane < KP) lse_s[lane] = l;
     } else {
         fill_two<T, HD, HD / AT<T>::EPC / 2>(qt, qbase, rstride, kt, qbase + C, rstride, RSTR, P.L, KP, lane, 64);
         fill_two<T, HD, HD / AT<T>::EPC / 2>(vt, qbase + 2 * C, rstride, dot_, dobase, ostride, RSTR, P.L, KP, lane, 64);
@@ -673,25 +645,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
             const float4 b = *reinterpret_cast<const float4*>(st_bias + j * C + P.h * HD + d);
             vec_reg = make_uint4(pack_bf2(r.x, r.y), pack_bf2(r.z, r.w), pack_bf2(-b.x, -b.y), pack_bf2(-b.z, -b.w));
         }
-        {   // per-row statistics: lse and delta = sum_d dO * O (one row per lane, all loads in flight together)
-            const int q = lane;
-            if (q < KP) {
-                float l = 0.f, dl = 0.f;
-                if (q < P.L) {
-                    l = lse[(P.tok0 + (size_t)q * P.tstep) * H + P.h];
-                    const T* a = dobase + (size_t)q * ostride;
-                    const T* b = obase + (size_t)q * ostride;
-                    float x[HD / 4][4], y[HD / 4][4];
-#pragma unroll
-                    for (int d = 0; d < HD / 4; ++d) { load4<T>(a + 4 * d, x[d]); load4<T>(b + 4 * d, y[d]); }
-#pragma unroll
-                    for (int d = 0; d < HD / 4; ++d)
-                        dl = fmaf(x[d][0], y[d][0], fmaf(x[d][1], y[d][1], fmaf(x[d][2], y[d][2], fmaf(x[d][3], y[d][3], dl))));
-                }
-                lse_s[q] = l;
-                del_s[q] = dl;
-            }
-        }
+        if (lane < KP) lse_s[lane] = lane < P.L ? lse[(P.tok0 + (size_t)lane * P.tstep) * H + P.h] : 0.f;
     }
     __syncthreads();
     const bool rvalid = pvalid && i < P.L;          // this lane's sequence element (query in pass 1, key in pass 2)
@@ -703,7 +657,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
         BReg<T, HD> qreg, doreg;
         qreg.load(reinterpret_cast<const T*>(qt + (size_t)i * RSTR), g, true);
         doreg.load(reinterpret_cast<const T*>(dot_ + (size_t)i * RSTR), g, true);
-        const float lq = lse_s[i], delta = del_s[i];
+        const float lq = lse_s[i];
         f32x16_t sf, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sf[r] = 0.f; dp[r] = 0.f; }
@@ -713,13 +667,22 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
             for (int r = 0; r < 16; ++r) dq[df][r] = 0.f;
         MmaRows<T, HD>::run(kt, RSTR, 0, qreg, lane, sf);
         MmaRows<T, HD>::run(vt, RSTR, 0, doreg, lane, dp);
+        float dl = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = (r & 3) + 8 * (r >> 2) + 4 * g;
             const float pr = (rvalid && key < P.L) ? __expf(sf[r] * scale - lq) : 0.f;
             const float dpr = DROP ? dp[r] * drop_mul(dr, P.dbase, min(i, P.L - 1), min(key, P.L - 1), P.L) : dp[r];
-            sf[r] = pr * (dpr - delta) * scale;
+            sf[r] = pr;
+            dp[r] = dpr;
+            dl = fmaf(pr, dpr, dl);
         }
+        // delta = rowsum(P o dP) -- the same number as dO . O (O = P V, dP = dO V^T), taken from the fragments this lane and its
+        // partner (lane ^ 32: the other half of the keys) already hold: O is not read at all (round 3: -270 MB per launch)
+        const float delta = wave_halves<WaveAdd>(dl);
+        if (g == 0) del_s[i] = delta;      // for pass 2 (lane = key): same wave, LDS operations execute in order
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sf[r] = sf[r] * (dp[r] - delta) * scale;
 #pragma unroll
         for (int df = 0; df < HD / 32; ++df) MmaCols<T>::run(kt, RSTR, df * 32, 0, sf, lane, dq[df]);
     }

@@ -31,7 +31,9 @@ def main():
     for name, mode in (('spatial', MODE_SPATIAL), ('temporal', MODE_TEMPORAL)):
         fwd = lambda: ops.attn_fwd(qkv, o, lse, B, T, J, H, scale, mode)
         bwd = lambda: ops.attn_bwd(qkv, o, d_o, lse, dqkv, B, T, J, H, scale, mode)
-        for tag, fn, nbytes in (('fwd', fwd, M * (3 * C + C) * 2 + M * H * 4), ('bwd', bwd, M * (3 * C + 2 * C + 3 * C) * 2 + M * H * 4)):
+        # backward: qkv, dO, dqkv, lse -- and O (delta = dO . O) in the temporal kernels; the one-wave kernel takes delta from P o dP
+        bwd_bytes = M * (3 * C + C + 3 * C + (0 if mode == MODE_SPATIAL else C)) * 2 + M * H * 4
+        for tag, fn, nbytes in (('fwd', fwd, M * (3 * C + C) * 2 + M * H * 4), ('bwd', bwd, bwd_bytes)):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
