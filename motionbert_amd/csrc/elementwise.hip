@@ -1229,69 +1229,71 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int n = Dout * R + 8;
     // zero this wave's LDS accumulator rows (dw accumulates in LDS-free registers per output i below)
     float* mine = lds + (size_t)wave * n;
-    float gb[HEAD_MAXD];
+    // Round 3: the rows of `rep` are read ONCE per group of four output channels (one pass for the model's dim_out = 3; the round-2
+    // kernel walked them once per channel and once more for dpre: 2.1 GB instead of 0.8 GB per launch).  The first pass also writes
+    // dpre; the weight-gradient rows of a group live in 4 x VPL x 4 registers.
+    constexpr int DG = 4;
+    for (int i0 = 0; i0 < Dout; i0 += DG) {
+        float gw[DG][VPL][4], gbv[DG];
 #pragma unroll
-    for (int i = 0; i < HEAD_MAXD; ++i) gb[i] = 0.f;
-    for (int i = 0; i < Dout; ++i) {
-        // one output channel at a time keeps the register footprint independent of Dout
-        float ww[VPL][4], gw[VPL][4];
-        ROW_LOOP(k) {
-            const int c = ROW_C(k);
+        for (int j = 0; j < DG; ++j) {
+            gbv[j] = 0.f;
+            ROW_LOOP(k) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { gw[k][e] = 0.f; ww[k][e] = 0.f; }
-            if (c < R) load4<float>(w + (size_t)i * R + c, ww[k]);
+                for (int e = 0; e < 4; ++e) gw[j][k][e] = 0.f;
+            }
         }
-        float gbi = 0.f;
         for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-            const float dv = dout[(size_t)row * Dout + i];
-            gbi += dv;
+            float dvg[DG];
+#pragma unroll
+            for (int j = 0; j < DG; ++j) dvg[j] = i0 + j < Dout ? dout[(size_t)row * Dout + i0 + j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < DG; ++j) gbv[j] += dvg[j];
+            float dv[HEAD_MAXD];
+            if (i0 == 0) {
+#pragma unroll
+                for (int q = 0; q < HEAD_MAXD; ++q) dv[q] = q < DG ? dvg[q < DG ? q : 0] : (q < Dout ? dout[(size_t)row * Dout + q] : 0.f);
+            }
             ROW_LOOP(k) {
                 const int c = ROW_C(k);
                 if (c < R) {
                     float r[4];
                     load4<float>(rep + (size_t)row * R + c, r);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) gw[k][e] = fmaf(dv, r[e], gw[k][e]);
-                }
-            }
-        }
+                    for (int j = 0; j < DG; ++j)
 #pragma unroll
-        for (int q = 0; q < HEAD_MAXD; ++q)
-            if (q == i) gb[q] = gbi;
-        ROW_LOOP(k) {
-            const int c = ROW_C(k);
-            if (c < R) store4<float>(mine + (size_t)i * R + c, gw[k]);
-        }
-    }
-    if (lane == 0) {
+                        for (int e = 0; e < 4; ++e) gw[j][k][e] = fmaf(dvg[j], r[e], gw[j][k][e]);
+                    if (i0 == 0) {      // dpre = (dout . w) (1 - rep^2): all Dout weights, once
+                        float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < HEAD_MAXD; ++q) mine[Dout * R + q] = gb[q];
-    }
-    // dpre: one pass over the rows with all Dout weights
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        float dv[HEAD_MAXD];
+                        for (int q = 0; q < HEAD_MAXD; ++q) {
+                            if (q < Dout) {
+                                float ww[4];
+                                load4<float>(w + (size_t)q * R + c, ww);
 #pragma unroll
-        for (int q = 0; q < HEAD_MAXD; ++q) dv[q] = q < Dout ? dout[(size_t)row * Dout + q] : 0.f;
-        ROW_LOOP(k) {
-            const int c = ROW_C(k);
-            if (c < R) {
-                float r[4], o[4] = {0.f, 0.f, 0.f, 0.f};
-                load4<float>(rep + (size_t)row * R + c, r);
+                                for (int e = 0; e < 4; ++e) o[e] = fmaf(dv[q], ww[e], o[e]);
+                            }
+                        }
 #pragma unroll
-                for (int q = 0; q < HEAD_MAXD; ++q) {
-                    if (q < Dout) {
-                        float ww[4];
-                        load4<float>(w + (size_t)q * R + c, ww);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = fmaf(dv[q], ww[e], o[e]);
+                        for (int e = 0; e < 4; ++e) o[e] *= (1.0f - r[e] * r[e]);
+                        store4<T>(dpre + (size_t)row * R + c, o);
                     }
                 }
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] *= (1.0f - r[e] * r[e]);
-                store4<T>(dpre + (size_t)row * R + c, o);
+        for (int j = 0; j < DG; ++j) {
+            if (i0 + j < Dout) {
+                ROW_LOOP(k) {
+                    const int c = ROW_C(k);
+                    if (c < R) store4<float>(mine + (size_t)(i0 + j) * R + c, gw[j][k]);
+                }
+                if (lane == 0) mine[Dout * R + i0 + j] = gbv[j];
             }
         }
     }
+    if (lane == 0)
+        for (int q = Dout; q < 8; ++q) mine[Dout * R + q] = 0.f;      // the unused tail of the [db 8] block
     __syncthreads();
     block_fold_store(lds, n, part + (size_t)blockIdx.x * n);
 }
