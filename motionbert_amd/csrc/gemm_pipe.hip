@@ -301,6 +301,9 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
     {
         const int row = wave * 16 + lr;
         srcW = W + (size_t)min(n0 + row, N - 1) * K + ((lp ^ ((row >> 2) & 3)) << 3);
+        // dbg 64 (timing probe only, results are wrong): read W as if it were packed k-tile-major, [N/16][K/32][16][32] -- one
+        // LDS-DMA instruction = one contiguous KiB (eight whole lines) instead of sixteen half lines
+        if (dbg & 64) srcW = W + (size_t)(min(n0 / 16 + wave, N / 16 - 1)) * (K / P_BK) * 512 + lane * 8;
     }
     char* dstA = smem + wave * 32 * P_ROWB;               // + stage * P_STAGE + i * 1024
     char* dstW = smem + P_A_BYTES + wave * 16 * P_ROWB;   // + stage * P_STAGE
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
         const size_t ko_ = (size_t)(kt_) * P_BK;                                       \
         GLDS16(srcA[0] + ko_, dstA + (stage_) * P_STAGE);                              \
         GLDS16(srcA[1] + ko_, dstA + (stage_) * P_STAGE + 1024);                       \
-        GLDS16(srcW + ko_, dstW + (stage_) * P_STAGE);                                 \
+        GLDS16(srcW + ((dbg & 64) ? (size_t)(kt_) * 512 : ko_), dstW + (stage_) * P_STAGE); \
     } while (0)
 
     // dbg bits (diagnostics only, MBX_DBG env): 1 = skip MFMA block, 2 = skip LDS-DMA, 4 = skip epilogue
