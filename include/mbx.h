@@ -41,7 +41,9 @@ enum mbx_epilogue {
     MBX_EPI_TANH  = 3, /* out_f = tanh(acc + bias)                    pre_logits fc + Tanh (:294-297,354)  */
     MBX_EPI_DGELU = 4, /* out_t = acc * gelu_erf'(aux_t)              backward of nn.GELU                  */
     MBX_EPI_LNBWD = 5, /* internal to mbx_gemm_nt_lnbwd (LayerNorm backward as a GEMM epilogue); not accepted by mbx_gemm_nt */
-    MBX_EPI_RESID_LN = 6 /* internal to mbx_gemm_nt_resid_ln (residual GEMM + the next LayerNorm forward); not accepted by mbx_gemm_nt */
+    MBX_EPI_RESID_LN = 6, /* internal to mbx_gemm_nt_resid_ln (residual GEMM + the next LayerNorm forward); not accepted by mbx_gemm_nt */
+    MBX_EPI_RESID_T = 7,  /* internal to mbx_gemm_nt_resid_t (MBX_EPI_RESID + a bf16 copy of the output); not accepted by mbx_gemm_nt */
+    MBX_EPI_STORE_LN = 8  /* internal to mbx_gemm_nt_rawln (LayerNorm row constants applied in the epilogue); not accepted by mbx_gemm_nt */
 };
 
 enum mbx_attn_mode {
@@ -134,6 +136,35 @@ int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat, const floa
 size_t mbx_unfold_norm_grads_ws(int N, int K);
 int mbx_unfold_norm_grads(float* dw, const float* db, const float* w, const float* gamma, const float* beta,
                           float* dgamma, float* dbeta, int N, int K, void* ws, void* stream);
+
+/* ---- LayerNorm as a raw operand + the fused MLP forward (bf16, no-grad / inference path) -------------------------------------
+ * One step beyond the folding above.  With W' = W diag(gamma), b' = b + W beta, rsum[n] = sum_k W'[n,k] (mbx_fold_norm_weights):
+ *     Linear(LayerNorm(y)) = rstd (y . W'^T - mean rsum) + b',
+ * so the PRODUCER of a residual-stream tensor y (DSTformer.py:241-249: x + attn(..), x + mlp(..)) only leaves bf16(y) beside the
+ * fp32 y, and the CONSUMER (the qkv / fc1 Linear behind norm1 / norm2) applies the row constants where its accumulators are:
+ * the 32 stand-alone LayerNorm passes of a forward (read fp32 y, write bf16 xhat) disappear.
+ *
+ * mbx_gemm_nt_resid_t: MBX_EPI_RESID (y f32 = resid + a . w^T + bias) + y_t = bf16(y).  N % 8 == 0, K % 64 == 0.
+ * mbx_gemm_nt_rawln:   out_t bf16 [M,N] = rstd[m] (a . w^T - mean[m] rsum[n]) + bias[n]; a = bf16(y) [M,K] raw, (mean, rstd) the
+ *                      LayerNorm statistics of the rows of y (f32 [M]), w / bias / rsum from mbx_fold_norm_weights.  N >= 256.
+ * mbx_mlp_fused_fwd:   the whole MLP sub-layer of a Block (MLP.forward, DSTformer.py:79-85, inside :242 / :244 / :246 / :248)
+ *     y = resid + fc2(gelu_erf(fc1(LN(.)))) in ONE kernel -- the [M, hidden] tensor never exists in HBM:
+ *       a        bf16 [M,C]: raw_in = 0: the normalised operand xhat (mbx_layernorm_fwd / mbx_fuse_ln_fwd with gamma = NULL);
+ *                            raw_in = 1: bf16(x) itself; mean / rstd of the row are taken in the kernel from these values
+ *       packed   the fc1 (folded) and fc2 weights in MFMA-fragment order: mbx_mlp_pack_weights(w1 bf16 [hidden,C], w2 bf16 [C,hidden])
+ *                -> mbx_mlp_pack_bytes(C, hidden) bytes
+ *       b1 [hidden] (folded bias b'), b2 [C], rsum [hidden] (raw_in only), resid f32 [M,C] (= x; may alias y)
+ *       y f32 [M,C];  y_t bf16 [M,C] = bf16(y) or NULL;  mean, rstd f32 [M] = LayerNorm statistics of the rows of y (eps) or NULL
+ *     C in {256, 512}, hidden % 64 == 0, hidden <= 1536. */
+int mbx_gemm_nt_resid_t(const void* a, const void* w, const float* bias, const float* resid, float* y, void* y_t, int M, int N,
+                        int K, void* stream);
+int mbx_gemm_nt_rawln(const void* a, const void* w, const float* bias, const float* rsum, const float* mean, const float* rstd,
+                      void* out_t, int M, int N, int K, void* stream);
+size_t mbx_mlp_pack_bytes(int C, int hidden);
+int mbx_mlp_pack_weights(const void* w1, const void* w2, void* packed, int C, int hidden, void* stream);
+int mbx_mlp_fused_fwd(const void* a, int raw_in, const void* packed, const float* b1, const float* b2, const float* rsum,
+                      const float* resid, float* y, void* y_t, float eps, float* mean, float* rstd, int M, int C, int hidden,
+                      void* stream);
 
 /* g = gelu_erf(u), T-typed, n % 4 == 0: rebuilds the MLP's post-activation from the saved pre-activation in the engine's
  * low-memory (recompute) mode (nn.GELU, DSTformer.py:70,80-81). */

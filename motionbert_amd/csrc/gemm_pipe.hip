@@ -20,6 +20,7 @@
 //                  hardware with tools/probes/tr_probe.hip).  256 x 128 output tile, split over the
 //                  token dimension, fp32 partial tiles folded by colsum (deterministic, no atomics).
 #include "mbx_common.h"
+#include "gelu_fast.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -85,64 +86,6 @@ __device__ __forceinline__ uint4 epi_load_u4(const bf16_t* p) {
 #ifndef MBX_ST_LNB
 #define MBX_ST_LNB 0    // LayerNorm-backward epilogue
 #endif
-
-// erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below bf16 resolution);
-// erf(u / sqrt 2) and the Gaussian of GELU' share one exponential, exp(-u^2 / 2).
-__device__ __forceinline__ void erf_parts(float u, float& erf_v, float& gauss) {
-    const float x = fabsf(u) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
-    gauss = __expf(-0.5f * u * u);
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    erf_v = copysignf(fmaf(-poly, gauss, 1.0f), u);
-}
-__device__ __forceinline__ float gelu_fast(float u) {
-    float e, g;
-    erf_parts(u, e, g);
-    return 0.5f * u * (1.0f + e);
-}
-// GELU of two values at once for the forward epilogue of the 256x256 kernel, which is VALU-bound (~80 issue cycles per element with
-// gelu_fast: two quarter-rate transcendentals and six unpacked operations).  Abramowitz-Stegun 7.1.28,
-//     erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16,  |error| <= 3e-7,
-// needs no exponential, and every other operation is a packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32):
-//     gelu(u) = u Phi(u) = (u + |u| erf(|u| / sqrt 2)) / 2 = ((u + a) - a r^16) / 2,   a = |u|,  r = 1 / D(a),
-// with 2^(-k/2) folded into the coefficients of D.  ~54 issue cycles per element; fp32 evaluation error 7e-7 absolute.
-#ifndef MBX_GELU_PK
-#define MBX_GELU_PK 1
-#endif
-__device__ __forceinline__ mbx_f32x2_t gelu_fast2(mbx_f32x2_t u) {
-    const mbx_f32x2_t a = {fabsf(u[0]), fabsf(u[1])};
-    mbx_f32x2_t d = a * 5.382975e-06f + 4.8890636e-05f;      // a6 / 8, a5 / 2^2.5
-    d = d * a + 3.8003575e-05f;                               // a4 / 4
-    d = d * a + 3.2776264e-03f;                               // a3 / 2^1.5
-    d = d * a + 2.1141006e-02f;                               // a2 / 2
-    d = d * a + 4.9867347e-02f;                               // a1 / sqrt 2
-    d = d * a + 1.0f;
-    mbx_f32x2_t rr = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    rr = rr * rr; rr = rr * rr; rr = rr * rr; rr = rr * rr;   // r^16
-    return ((u + a) - a * rr) * 0.5f;
-}
-// GELU'(u) = Phi(u) + u phi(u) of two values at once (the GELU' epilogue): the 7.1.26 form of gelu_fast_grad with every
-// non-transcendental operation packed; erf(|u| / sqrt 2) gets its sign back with v_bfi.
-__device__ __forceinline__ mbx_f32x2_t gelu_fast_grad2(mbx_f32x2_t u) {
-    const mbx_f32x2_t a = {fabsf(u[0]), fabsf(u[1])};
-    const mbx_f32x2_t den = a * 0.23164189f + 1.0f;          // 0.3275911 / sqrt 2
-    const mbx_f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-    const mbx_f32x2_t w = (u * u) * -0.72134752044448170368f;   // -u^2 / 2 in base-2 units
-    const mbx_f32x2_t gauss = {__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
-    mbx_f32x2_t poly = t * 1.061405429f + -1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t + -0.284496736f;
-    poly = poly * t + 0.254829592f;
-    poly = poly * t;
-    const mbx_f32x2_t e = 1.0f - poly * gauss;               // erf(|u| / sqrt 2)
-    const mbx_f32x2_t se = {copysignf(e[0], u[0]), copysignf(e[1], u[1])};
-    return (u * gauss) * 0.39894228040143267794f + (se * 0.5f + 0.5f);
-}
-__device__ __forceinline__ float gelu_fast_grad(float u) {
-    float e, g;
-    erf_parts(u, e, g);
-    return fmaf(u * g, 0.39894228040143267794f, 0.5f * (1.0f + e));
-}
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
@@ -459,7 +402,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
         // RESID: all eight residual loads of this half are issued BEFORE the accumulators are staged, so their HBM latency
         // runs under the LDS round trip (clamped addresses, unconditional: out-of-range lanes never store)
         float4 rr[8];
-        if (EPI == MBX_EPI_RESID || EPI == MBX_EPI_RESID_LN) {
+        if (EPI == MBX_EPI_RESID || EPI == MBX_EPI_RESID_LN || EPI == MBX_EPI_RESID_T) {
 #pragma unroll
             for (int p = 0; p < 8; ++p)
                 rr[p] = epi_load_f4<MBX_LD_RES>(resid + (size_t)min(m0 + wm * 64 + p * 8 + erow0, M - 1) * N + min(n, N - 4));
@@ -486,9 +429,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                     store4<bf16_t>(out2_t + o, v);
-                } else if (EPI == MBX_EPI_RESID || EPI == MBX_EPI_RESID_LN) {
+                } else if (EPI == MBX_EPI_RESID || EPI == MBX_EPI_RESID_LN || EPI == MBX_EPI_RESID_T) {
                     v[0] += rr[p].x; v[1] += rr[p].y; v[2] += rr[p].z; v[3] += rr[p].w;
                     epi_store16<MBX_ST_RES>(out_f + o, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+                    if (EPI == MBX_EPI_RESID_T) store4<bf16_t>(out_t + o, v);      // the raw operand of the next sub-layer's Linear
                 } else if (EPI == MBX_EPI_TANH) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
@@ -624,11 +568,15 @@ __device__ __forceinline__ void nt_epilogue(f32x16_t (&acc)[NTN][4], char* er, c
 // such an epilogue is store-ISSUE bound, not bandwidth bound (guide T21): half the store instructions for the same bytes.
 // Staging tile: 32 rows x 64 bf16, row pitch 144 B (16-byte aligned rows for ds_read_b128); GELU stages two tiles.
 static constexpr int EB_PITCH = 64 * 2 + 16, EB_TILE = 32 * EB_PITCH;   // 4608 B
+// STORE_LN (the no-grad path): the A operand was the RAW bf16 row y and the LayerNorm in front of this Linear is applied here,
+//     out = rstd (acc - mean rsum[n]) + b'[n]   (W' = W diag(gamma), b' = b + W beta, rsum = row sums of the rounded W'),
+// with the row constants (mean, rstd) of y from its producer: rows are lanes in the accumulator layout, so they are two registers.
 template <int EPI, int NTN, bool FULL>
 __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* er, const float* __restrict__ bias,
                                                  bf16_t* __restrict__ out_t, bf16_t* __restrict__ out2_t, int M, int N,
-                                                 int row_base, int col_base, int lane) {
-    static_assert(EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU, "bf16 staging: STORE / GELU only");
+                                                 int row_base, int col_base, int lane, const float* __restrict__ ln_rsum = nullptr,
+                                                 const float* __restrict__ ln_mean = nullptr, const float* __restrict__ ln_rstd = nullptr) {
+    static_assert(EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU || EPI == MBX_EPI_STORE_LN, "bf16 staging: STORE / GELU / STORE_LN only");
     const int i = lane & 31, g = lane >> 5;
     const int rr = lane >> 3, cc = (lane & 7) * 8;
     char* er2 = er + EB_TILE;
@@ -643,18 +591,37 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                 bb[tn][q][0] = bb[tn][q][1] = bb[tn][q][2] = bb[tn][q][3] = 0.f;
                 if (bias && (FULL || nb < N)) load4<float>(bias + nb, bb[tn][q]);
             }
+        float rsm[EPI == MBX_EPI_STORE_LN ? 2 : 1][4][4];
+        if (EPI == MBX_EPI_STORE_LN) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nb = col_base + h * 64 + tn * 32 + 8 * q + 4 * g;
+                    rsm[tn][q][0] = rsm[tn][q][1] = rsm[tn][q][2] = rsm[tn][q][3] = 0.f;
+                    if (FULL || nb < N) load4<float>(ln_rsum + nb, rsm[tn][q]);
+                }
+        }
         const int n = col_base + h * 64 + cc;
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
+            float ln_rs = 1.f, ln_k = 0.f;
+            if (EPI == MBX_EPI_STORE_LN) {
+                const int mr = min(row_base + tm * 32 + i, M - 1);
+                ln_rs = ln_rstd[mr];
+                ln_k = -ln_rs * ln_mean[mr];
+            }
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[2 * h + tn][tm][4 * q + e] + bb[tn][q][e];
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = EPI == MBX_EPI_STORE_LN ? fmaf(ln_rs, acc[2 * h + tn][tm][4 * q + e], fmaf(ln_k, rsm[tn][q][e], bb[tn][q][e]))
+                                                       : acc[2 * h + tn][tm][4 * q + e] + bb[tn][q][e];
                     const int off = i * EB_PITCH + (tn * 32 + 8 * q + 4 * g) * 2;
-                    if (EPI == MBX_EPI_STORE) {
+                    if (EPI == MBX_EPI_STORE || EPI == MBX_EPI_STORE_LN) {
                         *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     } else {
                         if (out_t) *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
@@ -681,7 +648,7 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                 const int m = row_base + tm * 32 + p * 8 + rr;
                 if (FULL || (m < M && n < N)) {     // FULL: the wave's whole 128 x 64 NTN/2 block is inside the matrix (no branches)
                     const size_t o = (size_t)m * N + n;
-                    if (EPI == MBX_EPI_STORE) {
+                    if (EPI == MBX_EPI_STORE || EPI == MBX_EPI_STORE_LN) {
                         epi_store16<MBX_ST_PP>(out_t + o, t1[p]);
                     } else {
                         if (out_t) epi_store16<MBX_ST_PP>(out_t + o, t1[p]);
@@ -782,17 +749,18 @@ __device__ __forceinline__ void nt256_epilogue(f32x16_t (&acc)[2][4], char* smem
                                                TO* __restrict__ out_t, TO* __restrict__ out2_t, float* __restrict__ out_f,
                                                const float* __restrict__ resid, const TO* __restrict__ aux, int M, int N, int m0,
                                                int n0, int wave, int lane, const float* __restrict__ st_bias = nullptr,
-                                               const float* __restrict__ st_rsum = nullptr, float* __restrict__ st_part = nullptr) {
+                                               const float* __restrict__ st_rsum = nullptr, float* __restrict__ st_part = nullptr,
+                                               const float* __restrict__ ln_mean = nullptr, const float* __restrict__ ln_rstd = nullptr) {
     __builtin_amdgcn_s_barrier();   // every wave is done with the k-loop's LDS stages
     char* er = smem + wave * Q_EPI_WAVE_BYTES;
     const int row_base = m0 + (wave >> 2) * 128, col_base = n0 + (wave & 3) * 64;
     if constexpr (sizeof(TO) == 4) {      // fp32-class mode (bf16x3): every T-typed tensor is fp32
         nt_epilogue<EPI, 2, TO>(acc, er, bias, out_t, out2_t, out_f, resid, aux, M, N, row_base, col_base, lane);
-    } else if constexpr (EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU) {
+    } else if constexpr (EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU || EPI == MBX_EPI_STORE_LN) {
         if (row_base + 128 <= M && col_base + 64 <= N)
-            nt_epilogue_bf16<EPI, 2, true>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane);
+            nt_epilogue_bf16<EPI, 2, true>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane, st_rsum, ln_mean, ln_rstd);
         else
-            nt_epilogue_bf16<EPI, 2, false>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane);
+            nt_epilogue_bf16<EPI, 2, false>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane, st_rsum, ln_mean, ln_rstd);
     }
     else if constexpr (EPI == MBX_EPI_DGELU)
         nt_epilogue_dgelu<2>(acc, er, out_t, aux, M, N, row_base, col_base, lane, st_bias, st_rsum, st_part);
@@ -906,7 +874,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
                                                                const float* __restrict__ resid, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ aux,
                                                                int M, int N, int K, int ntn,
                                                                const float* __restrict__ st_bias, const float* __restrict__ st_rsum,
-                                                               float* __restrict__ st_part
+                                                               float* __restrict__ st_part, const float* __restrict__ ln_mean,
+                                                               const float* __restrict__ ln_rstd
 #ifdef MBX_DIAG
                                                                , long long* trace      // cycle stamps: diagnostic builds only
 #endif
@@ -1046,7 +1015,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
 #undef PSTAMP
     if (!trailing) __builtin_amdgcn_s_barrier();   // pairs with the trailing group's last phase
 
-    nt256_epilogue<EPI, TO>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane, st_bias, st_rsum, st_part);
+    nt256_epilogue<EPI, TO>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane, st_bias, st_rsum, st_part, ln_mean, ln_rstd);
 #ifdef MBX_DIAG
     if (trace != nullptr && blockIdx.x == 3000 && (tid == 0 || tid == 256)) {
         long long* const tr2 = trace + (tid == 256 ? 2048 : 0);
@@ -1066,7 +1035,8 @@ static int set_lds_attr(K kernel, size_t bytes, const char* who) {
 
 static int launch_nt256(const void* a, const void* w, const float* bias, int epi, void* out_t, void* out2_t, float* out_f,
                         const float* resid, const void* aux, int M, int N, int K, hipStream_t s, const float* st_bias = nullptr,
-                        const float* st_rsum = nullptr, float* st_part = nullptr) {
+                        const float* st_rsum = nullptr, float* st_part = nullptr, const float* ln_mean = nullptr,
+                        const float* ln_rstd = nullptr) {
     const int ntn = (N + Q_BN - 1) / Q_BN, ntm = (M + Q_BM - 1) / Q_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
     const size_t shm = Q_NSTAGE * Q_STAGE;
@@ -1092,7 +1062,7 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w,        \
                            (const bf16_t*)nullptr, (const bf16_t*)nullptr, bias,                                      \
                            (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn,          \
-                           st_bias, st_rsum, st_part MBX_Q_TRACE_ARG);                                                \
+                           st_bias, st_rsum, st_part, ln_mean, ln_rstd MBX_Q_TRACE_ARG);                              \
         break;
     switch (epi) {
         MBX_Q_CASE(MBX_EPI_STORE)
@@ -1100,6 +1070,7 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
         MBX_Q_CASE(MBX_EPI_RESID)
         MBX_Q_CASE(MBX_EPI_TANH)
         MBX_Q_CASE(MBX_EPI_DGELU)
+        MBX_Q_CASE(MBX_EPI_STORE_LN)
         default: return mbx_set_error("gemm_nt: unknown epilogue %d", epi);
     }
 #undef MBX_Q_CASE
@@ -1126,7 +1097,8 @@ int mbx_launch_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_hi, 
         if (set_lds_attr(gemm_nt_pp256_kernel<E, true>, shm, "gemm_nt_x3")) return 1;                                 \
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E, true>), grid, block, shm, s, (const bf16_t*)a_hi, (const bf16_t*)w_hi, \
                            (const bf16_t*)a_lo, (const bf16_t*)w_lo, bias, out_t, out2_t, out_f, resid, aux, M, N, K, ntn, \
-                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr MBX_X3_TRACE_ARG);           \
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const float*)nullptr,      \
+                           (const float*)nullptr MBX_X3_TRACE_ARG);                                                   \
         break;
     switch (epi) {
         MBX_X3_CASE(MBX_EPI_STORE)
@@ -1207,6 +1179,35 @@ extern "C" int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat,
 #endif
                        );
     MBX_LAUNCH_CHECK("gemm_nt_lnbwd");
+    return 0;
+}
+
+// out_t = rstd (a . Wt - mean rsum) + b: the Linear behind a LayerNorm whose input row arrives RAW (a = bf16(y)) with its row
+// statistics -- the consumer side of include/mbx.h "LayerNorm as a raw operand" (qkv of the no-grad path)
+extern "C" int mbx_gemm_nt_rawln(const void* a, const void* w, const float* bias, const float* rsum, const float* mean, const float* rstd,
+                                 void* out_t, int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(a && w && bias && rsum && mean && rstd && out_t, "gemm_nt_rawln: null pointer");
+    MBX_CHECK_ARG(M > 0 && N >= 256 && N % 8 == 0 && K > 0 && K % 64 == 0, "gemm_nt_rawln: bad shape M=%d N=%d K=%d (N >= 256, N %% 8, K %% 64)", M, N, K);
+    return launch_nt256(a, w, bias, MBX_EPI_STORE_LN, out_t, nullptr, nullptr, nullptr, nullptr, M, N, K, (hipStream_t)stream, nullptr, rsum,
+                        nullptr, mean, rstd);
+}
+// y = resid + a . Wt + b (fp32) and y_t = bf16(y): the residual GEMM of the no-grad path, whose consumer takes the LayerNorm of y
+// as a raw operand (include/mbx.h "LayerNorm as a raw operand")
+extern "C" int mbx_gemm_nt_resid_t(const void* a, const void* w, const float* bias, const float* resid, float* y, void* y_t, int M,
+                                   int N, int K, void* stream) {
+    MBX_CHECK_ARG(a && w && resid && y && y_t, "gemm_nt_resid_t: null pointer");
+    MBX_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && K > 0 && K % 64 == 0, "gemm_nt_resid_t: bad shape M=%d N=%d K=%d (N %% 8, K %% 64)", M, N, K);
+    const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
+    const size_t shm = P_NSTAGE * P_STAGE;
+    if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_RESID_T>, shm, "gemm_nt_resid_t")) return 1;
+    hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_RESID_T>), dim3((unsigned)ntn * ntm), dim3(512), shm, (hipStream_t)stream, (const bf16_t*)a,
+                       (const bf16_t*)w, bias, (bf16_t*)y_t, (bf16_t*)nullptr, y, resid, (const bf16_t*)nullptr, M, N, K, ntn,
+                       (const float4*)nullptr, (const float*)nullptr, NtLnTail{}
+#ifdef MBX_DIAG
+                       , 0, (long long*)nullptr
+#endif
+                       );
+    MBX_LAUNCH_CHECK("gemm_nt_resid_t");
     return 0;
 }
 

@@ -1,0 +1,449 @@
+// Fused MLP sub-layer, forward only (the no-grad / inference path):
+//     y = x + fc2(gelu(fc1(LayerNorm(x))))  and the statistics of LayerNorm(y) for the sub-layer that reads y next
+// (reference lib/model/DSTformer.py:79-85 MLP.forward inside Block.forward :241-249) as ONE kernel: the hidden [M, hidden]
+// tensor (pre- and post-activation) never exists in HBM, and the next LayerNorm costs no pass over y.
+// Per MLP the unfused kernel set moves  xhat 1 + (g 2 + 2) + x 2 + y 2 (+ the next LayerNorm: 2 + 1)  bf16-row units of HBM
+// traffic, this kernel  operand 1 + x 2 + y 2 + bf16(y) 1.
+//
+// LayerNorm as a "raw operand" (the folded form of include/mbx.h taken one step further): Linear(LayerNorm(y)) =
+// rstd (y . W'^T - mean rsum) + b' with W' = W diag(gamma), b' = b + W beta, rsum[n] = sum_k W'[n,k].  So a PRODUCER of the
+// residual stream only has to leave bf16(y) and the row statistics (mean, rstd) -- no second pass over the row -- and the
+// CONSUMER GEMM applies the row constants in its epilogue.  This kernel is both: with `mean_in / rstd_in` its fc1 takes the raw
+// bf16 rows of its producer (otherwise xhat from a LayerNorm kernel), and it always can emit bf16(y) + (mean, rstd) of its output.
+//
+// Structure ("row owner"): a workgroup = 4 waves, ONE per SIMD (the whole 512-entry register file per lane), 128 token rows;
+// wave w owns rows [32 w, 32 w + 32) COMPLETELY:
+//   * X  = its 32 x C slice of xhat as MFMA operand fragments, C/4 registers, loaded once through LDS;
+//   * per chunk of 64 hidden columns:  acc1[32 x 64] = X . W1c^T (2 x C/16 MFMAs 32x32x16), bias + GELU on the accumulator
+//     registers, and -- this is what keeps the hidden on chip -- the packed bf16 result IS the token operand of the second GEMM:
+//     in the transposed MFMA orientation used throughout this library (D = W-fragment x token-fragment, lane = token) lane (i, g)
+//     ends up holding hidden columns {8q + 4g + e} of token i, i.e. eight of the sixteen k-slots of two K = 16 steps, as long as
+//     W2's fragments list the hidden index in the same permuted order -- which the weight packer guarantees;
+//   * acc2[32 x C] += G . W2c^T (C/32 x 4 MFMAs), C/2 accumulator registers that live across all chunks;
+//   * epilogue: + bias + residual -> y (fp32) and bf16(y), mean / rstd over the wave's complete rows.
+// Register file (C = 512): acc2 256 + X 128 = 384 registers in the ACCUMULATOR half of the unified file (MFMA reads X from there
+// as its B operand), 128 VGPRs for acc1 (32), two generations of the packed hidden (32), eight weight fragments in flight (32) and
+// the GELU arithmetic.  hipcc cannot be talked into that split (its allocation of the plain-builtin version spills and shuffles
+// 2000+ v_accvgpr moves per tile), so the MFMAs are inline asm with explicit register classes (cdna_hip_programming.md 5.7);
+// everything else is compiler code.  What the asm statements own: the wait states between an MFMA chain and the first non-MFMA
+// reader of its result (the NOP statements below), and issue order (volatile statements keep source order, so the fragment reads
+// are software-pipelined by hand, PF fragments ahead).
+// Every wave multiplies ALL weight fragments with its own rows, so the weights stream through a 4 x 32 KiB LDS ring filled by
+// LDS-DMA; the packer (mlp_pack_kernel) lays them out as the exact sequence of 1-KiB MFMA fragments (lane-linear: lane l's
+// 16 bytes at 16 l) the loop consumes, so one DMA instruction moves one contiguous KiB and a fragment read is
+// `ds_read_b128 base + 16 lane + imm` -- conflict-free by construction, no address arithmetic.
+// Pipeline (GELU must overlap MFMAs of another chunk -- with one wave per SIMD nothing else covers it):
+//     A(0) gelu(0) | A(1) [B(0) || gelu(1)] | A(2) [B(1) || gelu(2)] | ... | A(n-1) [B(n-2) || gelu(n-1)] | B(n-1)
+// A(c) = fc1 of chunk c, B(c) = fc2 of chunk c; the weight stream is consumed in exactly this order, 32 fragments per stage,
+// ONE barrier per stage, placed at 3/4 of the stage so that the next stage's first fragments are read under this stage's last MFMAs.
+#include "mbx_common.h"
+#include "gelu_fast.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+// LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes -> 1 KiB of LDS at the wave-uniform address in M0) as an asm statement.
+// Through the builtin hipcc books every DMA as an LDS event of a second kind: it then waits lgkmcnt(0) instead of a counted
+// lgkmcnt(N) in front of every MFMA (the fragment prefetch would be drained seven slots out of eight) and vmcnt(0) in front of LDS
+// reads it cannot tell apart from the DMA's destination.  As asm the DMA is invisible to that pass; the kernel owns its vmcnt
+// (the counted waits of MF_SYNC) -- cdna_hip_programming.md 5.7: M0 is written and restored inside the statement.
+__device__ __forceinline__ void glds16(const void* src, const void* lds_dst) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(uintptr_t)(const lds_void_t*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+#define GLDS16(src, dst) glds16((src), (dst))
+
+static constexpr int F_BM = 128;               // token rows per workgroup (4 waves x 32)
+static constexpr int F_STAGE = 32 * 1024;      // one ring stage = 32 fragments of 1 KiB
+static constexpr int F_RING = 4 * F_STAGE;     // 128 KiB
+static constexpr int F_CH = 64;                // hidden columns per chunk
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // one MFMA operand fragment (8 bf16)
+
+// ---- packed weight stream ---------------------------------------------------------------------------------------------------
+// chunk c (hidden columns [64 c, 64 c + 64)) = C/4 fragments: first the fc1 part, fragment (s, tn) at index 2 s + tn
+// (s = k-step of 16 input channels, tn = 32-column half of the chunk), then the fc2 part, fragment (kk, nt) at index
+// kk C/32 + nt (kk = one of the chunk's four K = 16 steps, nt = 32-column tile of the output).  Inside a fragment lane
+// l = (i, g) = (l & 31, l >> 5) owns bytes [16 l, 16 l + 16):
+//   fc1 (s, tn):  W1[64 c + 32 tn + i][16 s + 8 g + t],                                   t = 0..7
+//   fc2 (kk, nt): W2[32 nt + i][64 c + 32 (kk >> 1) + 16 (kk & 1) + 8 (t >> 2) + 4 g + (t & 3)]
+// -- the hidden index that lane (., g) of the fc1 accumulator holds in registers 4 q + e, q = 2 (kk & 1) + (t >> 2), e = t & 3.
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
+                                                       bf16_t* __restrict__ out, int C, int hidden) {
+    const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int per_chunk = C / 4, fa = C / 8;                  // fragments per chunk (fc1: C/16 k-steps x 2, fc2: 4 x C/32), of which fc1
+    if (frag >= hidden / F_CH * per_chunk) return;
+    const int c = frag / per_chunk, f = frag % per_chunk;
+    const int i = lane & 31, g = lane >> 5;
+    uint4 v;
+    if (f < fa) {
+        const int s = f >> 1, tn = f & 1;
+        v = *reinterpret_cast<const uint4*>(w1 + (size_t)(F_CH * c + 32 * tn + i) * C + 16 * s + 8 * g);
+    } else {
+        const int nt2 = C / 32, kk = (f - fa) / nt2, nt = (f - fa) % nt2;
+        const bf16_t* p = w2 + (size_t)(32 * nt + i) * hidden + F_CH * c + 32 * (kk >> 1) + 16 * (kk & 1) + 4 * g;
+        const uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 8);
+        v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)frag * 512 + lane * 8) = v;
+}
+
+// XOR applied to the 16-byte piece index of the X image so that the fragment reads (32 rows, one piece each) are conflict-free
+// for ds_read_b128's 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}: rows r = i & 7 of row group rb = i >> 3
+__device__ __forceinline__ int x_swz(int r, int rb) { return ((r >> 1) & 3) | (((rb >> 1) & 1) << 2); }
+
+// two bias floats from the LDS copy (read as a dword pair through the same kind of access as the fragment reads)
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 ge_bias_ld(const char* p) {
+    const u32x2_t v = *reinterpret_cast<const u32x2_t*>(p);
+    return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
+
+// MFMA statements.  D = A(weights fragment, VGPR) x B(token fragment) + C.  fc1: accumulator in VGPRs (the GELU reads it), token
+// operand X in accumulator registers; fc2: accumulator in accumulator registers, token operand = the packed hidden (VGPR).
+// The *_Z forms start a chain from zero (no register initialisation, hence no write -> MFMA wait state to own).
+#define MFMA_FC1_Z(acc_, w_, x_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc_) : "v"(w_), "v"(x_))
+#define MFMA_FC1(acc_, w_, x_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc_) : "v"(w_), "v"(x_))
+#define MFMA_FC2_Z(acc_, w_, g_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc_) : "v"(w_), "v"(g_))
+#define MFMA_FC2(acc_, w_, g_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc_) : "v"(w_), "v"(g_))
+// wait states between the last MFMA that writes a register and its first non-MFMA reader / writer (8-pass XDL: 12; 16 taken)
+#define MFMA_PAD_V(a_, b_) asm volatile("s_nop 15" : "+v"(a_), "+v"(b_))
+#define MFMA_PAD_A(a_) asm volatile("s_nop 15" : "+a"(a_))
+
+template <int C>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restrict__ xh, const char* __restrict__ wpk,
+                                                           const float* __restrict__ b1, const float* __restrict__ b2,
+                                                           const float* __restrict__ rsum, int raw_in, const float* resid, float* y,
+                                                           bf16_t* __restrict__ yb_out, float eps, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, int M, int hidden) {
+    constexpr int NT2 = C / 32;            // 32-column tiles of the output row
+    constexpr int KS = C / 16;             // fc1 k-steps
+    constexpr int S2 = C / 256;            // stages per fc1 part and per fc2 part of a chunk
+    constexpr int KKS = 32 / NT2;          // fc2 k-steps per stage
+    constexpr int CHB = 2 * S2 * F_STAGE;  // bytes of one chunk of the stream
+    constexpr int NH = C / 256;            // 256-column halves of the output row (epilogue)
+    constexpr int GSTEPS = 2 / S2;         // GELU micro-steps per fc2 slot (64 per chunk over S2 * 32 slots)
+    constexpr int XL = C == 512 ? 4 : 0;   // the last XL fragments of X are kept in LDS and visit registers only around their use (the
+                                           // second fc1 stage): the GELU stages, where every VGPR is spoken for, do not carry them
+    constexpr int PF = 5;                  // weight fragments in flight ahead of the MFMA that consumes them
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ring 128 KiB | b1 [hidden] | rsum [hidden] | b2 [C] | XL KiB per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    const int m0 = blockIdx.x * F_BM, mw = m0 + 32 * wave;
+    char* const ring = smem;
+    float* const b1s = reinterpret_cast<float*>(smem + F_RING);
+    float* const rss = b1s + hidden;
+    float* const b2s = rss + hidden;
+    char* const xsp = reinterpret_cast<char*>(b2s + C) + wave * (XL * 1024) + lane * 16;
+    const int nch = hidden / F_CH, NS = nch * 2 * S2;
+
+    for (int k = tid; k < hidden; k += 256) { b1s[k] = b1[k]; rss[k] = raw_in ? rsum[k] : 0.f; }
+    for (int k = tid; k < C; k += 256) b2s[k] = b2[k];
+
+    // ---- X: the wave's 32 rows of xhat -> LDS (wave-private image, whole 128-byte lines per DMA) -> operand fragments --------
+    char* const ximg = ring + wave * (64 * C);
+    {
+        const int xr = lane >> 3, xp = lane & 7;
+#pragma unroll 4
+        for (int j = 0; j < KS; ++j) {             // one instruction = 8 rows x 128 B: row group rb = j & 3, column segment j >> 2
+            const int rb = j & 3, cs = j >> 2;
+            const int row = min(mw + 8 * rb + xr, M - 1);
+            GLDS16(xh + (size_t)row * C + cs * 64 + ((xp ^ x_swz(xr, rb)) << 3), ximg + j * 1024);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u32x4_t X[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int rb = i >> 3, r = i & 7, p = 2 * (s & 3) + g;
+        X[s] = *reinterpret_cast<const u32x4_t*>(ximg + ((s >> 2) * 4 + rb) * 1024 + r * 128 + ((p ^ x_swz(r, rb)) << 4));
+    }
+    // Row constants of the raw-operand LayerNorm: fc1 = rstd acc + (b' - rstd mean rsum).  With raw_in the operand rows are bf16(y)
+    // and (mean, rstd) are taken HERE, from the very values the MFMAs will multiply (lane (i, g) holds half of row i: packed-bf16
+    // dots with ones / with itself, fp32 sums, the halves joined across lane ^ 32); otherwise the operand is already normalised
+    // and the constants are (1, 0): fc1 = 1 acc + (b' + 0 rsum).
+    float ln_rs = 1.f, ln_k = 0.f;
+    if (raw_in) {                                  // wave-uniform
+        float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sa = dot2_bf16(X[s][0], 0x3f803f80u, sa); qa = dot2_bf16(X[s][0], X[s][0], qa);
+            sb = dot2_bf16(X[s][1], 0x3f803f80u, sb); qb = dot2_bf16(X[s][1], X[s][1], qb);
+            sa = dot2_bf16(X[s][2], 0x3f803f80u, sa); qa = dot2_bf16(X[s][2], X[s][2], qa);
+            sb = dot2_bf16(X[s][3], 0x3f803f80u, sb); qb = dot2_bf16(X[s][3], X[s][3], qb);
+        }
+        const float st = wave_halves<WaveAdd>(sa + sb), qt = wave_halves<WaveAdd>(qa + qb);
+        const float mu = st * (1.0f / (float)C);
+        ln_rs = 1.0f / sqrtf(fmaxf(qt * (1.0f / (float)C) - mu * mu, 0.f) + eps);
+        ln_k = -ln_rs * mu;
+    }
+#pragma unroll
+    for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // every wave has its X; the biases are in LDS; the ring is free
+
+    // ---- weight stream -------------------------------------------------------------------------------------------------------
+    // stage sequence q -> byte offset in the packed stream:  A(0) | A(1) B(0) | A(2) B(1) | ... | A(n-1) B(n-2) | B(n-1)
+    // (past the end: a harmless re-read of the last stage into a slot nobody reads again, so that the wait counts stay constant)
+    auto seq_off = [&](int qq) -> int {
+        const int qc = min(qq, NS - 1), k = qc - S2, grp = k / (2 * S2), r = k % (2 * S2);
+        const int mid = (r < S2 ? grp + 1 : grp) * CHB + r * F_STAGE;
+        const int last = (nch - 1) * CHB + (S2 + r) * F_STAGE;
+        return qc < S2 ? qc * F_STAGE : (grp >= nch - 1 ? last : mid);
+    };
+    const char* const wl = wpk + wave * 1024 + lane * 16;       // this lane's 16 bytes of piece d (fragments 4 d + wave) of a stage
+    char* const dl = ring + wave * 1024;
+#define MF_ISSUE1(src_, slot_, d_) GLDS16((src_) + (d_) * 4096, dl + (slot_) * F_STAGE + (d_) * 4096)
+    // stage q + 1 has landed (this wave's pieces: counted wait; everyone's: barrier) and everyone is done with stage q - 1
+#define MF_SYNC(n_)                                                                                                  \
+    do {                                                                                                             \
+        asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+
+    f32x16_t acc2[NT2];
+    f32x16_t acc1[2];
+    // packed hidden: the fc2 of chunk c - 1 reads G[0..3] in order while the GELU of chunk c produces its four fragments in order;
+    // fragment n + 1 of the new generation goes into the registers of fragment n of the old one (dead by then), fragment 0 into G[4]
+    u32x4_t G[5];
+    u32x4_t fb[8];                                              // weight fragments: slot k of a stage lives in fb[k & 7] (PF + 1 of them alive)
+    u32x4_t xl[XL > 0 ? XL : 1];                                // the LDS-resident fragments of X, in registers during the second fc1 stage only
+    const char* const fr = ring + lane * 16;                    // fragment f of ring slot s: fr + s * F_STAGE + f * 1024
+
+    int q = 0;                                                  // stage sequence number
+    {
+        const char* const s0 = wl + seq_off(0);
+        const char* const s1 = wl + seq_off(1);
+        const char* const s2 = wl + seq_off(2);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) MF_ISSUE1(s0, 0, d);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) MF_ISSUE1(s1, 1, d);
+        MF_ISSUE1(s2, 2, 0);
+        MF_ISSUE1(s2, 2, 1);
+    }
+    MF_SYNC(10);                                                // stage 0 is in LDS
+#pragma unroll
+    for (int k = 0; k < PF; ++k) fb[k] = *reinterpret_cast<const u32x4_t*>(fr + k * 1024);
+
+    // One stage = 32 slots.  Slot k: read the fragment of slot k + PF (from slot 32 - PF on, a fragment of the NEXT stage: the
+    // barrier sits in front of slot 24), one MFMA, every fourth slot one LDS-DMA piece (slots 3..23: pieces 2..7 of stage q + 2,
+    // slots 27, 31: pieces 0, 1 of stage q + 3), then HOOK_ (GELU micro-steps); sched_barrier(0) pins the slot.
+#define MF_STAGE(MMA_, HOOK_)                                                                                        \
+    do {                                                                                                             \
+        const char* const st_ = fr + (q & 3) * F_STAGE;                                                              \
+        const char* const sn_ = fr + ((q + 1) & 3) * F_STAGE;                                                        \
+        const char* const n2_ = wl + seq_off(q + 2);                                                                 \
+        const char* const n3_ = wl + seq_off(q + 3);                                                                 \
+        const int l2_ = (q + 2) & 3, l3_ = (q + 3) & 3;                                                              \
+        _Pragma("unroll") for (int k_ = 0; k_ < 32; ++k_) {                                                          \
+            if (k_ == 24) MF_SYNC(8);                                                                                \
+            fb[(k_ + PF) & 7] = *reinterpret_cast<const u32x4_t*>(k_ + PF < 32 ? st_ + (k_ + PF) * 1024 : sn_ + (k_ + PF - 32) * 1024); \
+            MMA_(k_, fb[k_ & 7]);                                                                                    \
+            if ((k_ & 3) == 3) { if (k_ < 24) MF_ISSUE1(n2_, l2_, (k_ >> 2) + 2); else MF_ISSUE1(n3_, l3_, (k_ >> 2) - 6); } \
+            HOOK_(k_);                                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        ++q;                                                                                                         \
+    } while (0)
+
+    // ---- GELU of acc1 (+ bias) -> the next generation of G, as 64 micro-steps of ~7 VALU operations: pair j = 0..15 (two accumulator registers), four
+    // steps per pair (A&S 7.1.28 as in gelu_fast2: polynomial / polynomial + reciprocal / r^16 / combine + pack).  Pair j: column
+    // half tn = j >> 3, register quad qq = (j >> 1) & 3, registers 4 qq + 2 (j & 1) + {0, 1}.
+    mbx_f32x2_t ge_u, ge_a, ge_d;
+    float2 ge_b = make_float2(0.f, 0.f), ge_r = make_float2(0.f, 0.f);   // bias / rsum of the next pair, read right after the current pair took its own
+    int gc = 0;                                                 // chunk whose GELU runs (bias index)
+#define GE_BIAS(j_) ge_bias_ld(smem + F_RING + 16 * g + (gc * F_CH + ((j_) >> 3) * 32 + 8 * (((j_) >> 1) & 3) + 2 * ((j_) & 1)) * 4)
+#define GE_RSUM(j_) ge_bias_ld(smem + F_RING + 4 * hidden + 16 * g + (gc * F_CH + ((j_) >> 3) * 32 + 8 * (((j_) >> 1) & 3) + 2 * ((j_) & 1)) * 4)
+#define GE_LOAD(j_) do { ge_b = GE_BIAS(j_); ge_r = GE_RSUM(j_); } while (0)
+#define GE_STEP(ms_)                                                                                                 \
+    do {                                                                                                             \
+        const int j_ = (ms_) >> 2, st_ = (ms_) & 3, tn_ = j_ >> 3, qq_ = (j_ >> 1) & 3, r0_ = 4 * qq_ + 2 * (j_ & 1);  /* fold after unrolling */ \
+        if (st_ == 0) {                                                                                              \
+            ge_u = mbx_f32x2_t{fmaf(ln_rs, acc1[tn_][r0_], fmaf(ln_k, ge_r.x, ge_b.x)), fmaf(ln_rs, acc1[tn_][r0_ + 1], fmaf(ln_k, ge_r.y, ge_b.y))}; \
+            if (j_ + 1 < 16) GE_LOAD(j_ + 1);                     /* the next pair's constants: four slots ahead of their use */ \
+            ge_a = mbx_f32x2_t{fabsf(ge_u[0]), fabsf(ge_u[1])};                                                      \
+            ge_d = ge_a * 5.382975e-06f + 4.8890636e-05f;                                                            \
+            ge_d = ge_d * ge_a + 3.8003575e-05f;                                                                     \
+            ge_d = ge_d * ge_a + 3.2776264e-03f;                                                                     \
+        } else if (st_ == 1) {                                                                                       \
+            ge_d = ge_d * ge_a + 2.1141006e-02f;                                                                     \
+            ge_d = ge_d * ge_a + 4.9867347e-02f;                                                                     \
+            ge_d = ge_d * ge_a + 1.0f;                                                                               \
+            ge_d = mbx_f32x2_t{__builtin_amdgcn_rcpf(ge_d[0]), __builtin_amdgcn_rcpf(ge_d[1])};                      \
+        } else if (st_ == 2) {                                                                                       \
+            ge_d = ge_d * ge_d; ge_d = ge_d * ge_d; ge_d = ge_d * ge_d; ge_d = ge_d * ge_d;                          \
+        } else {                                                                                                     \
+            const mbx_f32x2_t o_ = ((ge_u + ge_a) - ge_a * ge_d) * 0.5f;                                             \
+            G[(tn_ * 2 + (qq_ >> 1) + 4) % 5][2 * (qq_ & 1) + (j_ & 1)] = pack_bf2(o_[0], o_[1]);                             \
+        }                                                                                                            \
+    } while (0)
+
+    // fc1 slot k of the stage's half h: k-step s = 16 h + (k >> 1), column half tn = k & 1
+#define MMA_A0(k_, w_) do { if ((k_) < 2) MFMA_FC1_Z(acc1[(k_) & 1], w_, X[(k_) >> 1]); else MFMA_FC1(acc1[(k_) & 1], w_, X[(k_) >> 1]); } while (0)
+#define MMA_A1(k_, w_) do { if (16 + ((k_) >> 1) >= KS - XL) MFMA_FC1(acc1[(k_) & 1], w_, xl[(XL > 0 ? 16 + ((k_) >> 1) - (KS - XL) : 0)]); \
+                            else MFMA_FC1(acc1[(k_) & 1], w_, X[16 + ((k_) >> 1)]); } while (0)
+#define HOOK_A1(k_) do { if (XL > 0 && (k_) >= 16 && (k_) < 16 + 2 * XL && !((k_) & 1)) xl[((k_) - 16) >> 1] = *reinterpret_cast<const u32x4_t*>(xsp + (((k_) - 16) >> 1) * 1024); } while (0)
+#define HOOK_NONE(k_) do { } while (0)
+    // fc2 slot k of the stage's part hb: k-step kk = hb KKS + k / NT2, output tile nt = k % NT2
+#define MMA_B0F(k_, w_) do { if ((k_) < NT2) MFMA_FC2_Z(acc2[(k_) % NT2], w_, G[(k_) / NT2]); else MFMA_FC2(acc2[(k_) % NT2], w_, G[(k_) / NT2]); } while (0)
+#define MMA_B0(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, G[(k_) / NT2])
+#define MMA_B1(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, G[KKS + (k_) / NT2])
+    // GELU micro-steps beside fc2 slot k of part hb (C = 512: one per slot; C = 256: two); the first slot also pads the fc1 chain
+#define HOOK_G0(k_) do { if ((k_) == 0) MFMA_PAD_V(acc1[0], acc1[1]); if (GSTEPS == 2) { GE_STEP(2 * (k_)); GE_STEP(2 * (k_) + 1); } else GE_STEP(k_); } while (0)
+#define HOOK_G1(k_) do { GE_STEP(32 + (k_)); } while (0)
+
+#define MF_PART_A()                                                                                                  \
+    do {                                                                                                             \
+        MF_STAGE(MMA_A0, HOOK_NONE);                                                                                 \
+        if constexpr (S2 == 2) MF_STAGE(MMA_A1, HOOK_A1);                                                            \
+    } while (0)
+
+    // A(0), gelu(0): the only GELU that overlaps nothing
+    MF_PART_A();
+    MFMA_PAD_V(acc1[0], acc1[1]);
+    GE_LOAD(0);
+#define GE_ALL4(b_) GE_STEP((b_)); GE_STEP((b_) + 1); GE_STEP((b_) + 2); GE_STEP((b_) + 3)
+#define GE_ALL16(b_) GE_ALL4(b_); GE_ALL4((b_) + 4); GE_ALL4((b_) + 8); GE_ALL4((b_) + 12)
+    GE_ALL16(0); GE_ALL16(16); GE_ALL16(32); GE_ALL16(48);
+#define G_ROTATE() do { asm volatile("s_nop 7" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3]), "+v"(G[4]));                       \
+                        G[3] = G[2]; G[2] = G[1]; G[1] = G[0]; G[0] = G[4];                                                         \
+                        asm volatile("s_nop 3" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3])); } while (0)
+    G_ROTATE();
+    if (nch > 1) {
+        // chunk 1: A(1), then B(0) (which starts the fc2 accumulators) || gelu(1)
+        MF_PART_A();
+        gc = 1;
+        GE_LOAD(0);
+        MF_STAGE(MMA_B0F, HOOK_G0);
+        if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_G1);
+        G_ROTATE();
+        for (int c = 2; c < nch; ++c) {
+            MF_PART_A();                   // A(c)
+            gc = c;
+            GE_LOAD(0);
+            MF_STAGE(MMA_B0, HOOK_G0);     // B(c - 1) || gelu(c)
+            if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_G1);
+            G_ROTATE();
+        }
+        MF_STAGE(MMA_B0, HOOK_NONE);       // B(n - 1)
+        if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_NONE);
+    } else {
+        MF_STAGE(MMA_B0F, HOOK_NONE);
+        if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_NONE);
+    }
+
+    // ---- epilogue: y = acc2 + b2 + x -> y (fp32), bf16(y), (mean, rstd) of the row ------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-read tail stages have landed, the last prefetches returned
+    __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) MFMA_PAD_A(acc2[t]);
+    // The accumulators are only READ here (any arithmetic ON them makes new 16-register values and spills).  Per 256-column half:
+    // the wave's 32 residual rows arrive in a wave-private LDS image by LDS-DMA (32 rows x 1 KiB, 16-byte piece p of row r at
+    // p ^ (r & 15): conflict-free both in the accumulator layout -- lane (i, g): row i, piece 8 ntl + 2 qq + g -- and row-major);
+    // each lane adds its accumulator values IN PLACE, taking the row statistics on the way (shifted sums per lane = half a row,
+    // the halves joined by Chan's formula at the end); then the image is walked row-major: one instruction = one row's KiB of y /
+    // 512 B of bf16(y).  One wave's LDS operations execute in order, so the image needs no barriers.
+    // (lane-derived values are re-derived from an opaque copy of the thread index: otherwise the compiler carries a dozen of them
+    // through the main loop, where every VGPR is spoken for)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63;
+#define lane lane_e
+    const int i_e = lane & 31, g_e = lane >> 5;
+#define i i_e
+#define g g_e
+    char* const er = ring + wave * 32768;
+    float sh = 0.f, s1 = 0.f, s2 = 0.f;
+    const int rows = min(32, M - mw);
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (second half: the row-major reads of the first one are done)
+#pragma unroll 4
+        for (int r = 0; r < 32; ++r)
+            GLDS16(resid + (size_t)min(mw + r, M - 1) * C + hh * 256 + ((lane ^ (r & 15)) << 2), er + r * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ntl = 0; ntl < 8; ++ntl) {
+            const int nt = hh * 8 + ntl;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                float4* const pp = reinterpret_cast<float4*>(er + i * 1024 + (((ntl * 8 + 2 * qq + g) ^ (i & 15)) << 4));
+                const float4 bb = *reinterpret_cast<const float4*>(b2s + nt * 32 + 8 * qq + 4 * g);
+                const float4 xv = *pp;
+                const float v0 = acc2[nt][4 * qq] + bb.x + xv.x, v1 = acc2[nt][4 * qq + 1] + bb.y + xv.y;
+                const float v2 = acc2[nt][4 * qq + 2] + bb.z + xv.z, v3 = acc2[nt][4 * qq + 3] + bb.w + xv.w;
+                *pp = make_float4(v0, v1, v2, v3);
+                if (hh == 0 && ntl == 0 && qq == 0) sh = v0;
+                const float d0 = v0 - sh, d1 = v1 - sh, d2 = v2 - sh, d3 = v3 - sh;
+                s1 += (d0 + d1) + (d2 + d3);
+                s2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, s2))));
+            }
+        }
+        float* const yrow = y + (size_t)mw * C + hh * 256;           // wave-uniform bases + a 32-bit lane offset
+        bf16_t* const brow = yb_out + (size_t)mw * C + hh * 256;
+#pragma unroll 4
+        for (int r = 0; r < rows; ++r) {
+            const float4 t = *reinterpret_cast<const float4*>(er + r * 1024 + ((lane ^ (r & 15)) << 4));
+            *reinterpret_cast<float4*>(yrow + (size_t)r * C + lane * 4) = t;
+            if (yb_out != nullptr)
+                *reinterpret_cast<uint2*>(brow + (size_t)r * C + lane * 4) = make_uint2(pack_bf2(t.x, t.y), pack_bf2(t.z, t.w));
+        }
+    }
+    if (mean_out != nullptr) {
+        constexpr float nh = (float)(C / 2);                          // values per lane
+        const float mean_h = sh + s1 / nh, m2_h = s2 - s1 * s1 / nh;  // this half row: mean, sum of squared deviations
+        const float mean_o = wave_halves<WaveAdd>(mean_h) - mean_h;   // the partner lane's half (lane ^ 32)
+        const float m2_both = wave_halves<WaveAdd>(m2_h);
+        const float delta = mean_o - mean_h;
+        const float var = fmaxf((m2_both + delta * delta * (nh * 0.5f)) / (float)C, 0.f);
+        if (g == 0 && i < rows) {
+            mean_out[mw + i] = 0.5f * (mean_h + mean_o);
+            rstd_out[mw + i] = 1.0f / sqrtf(var + eps);
+        }
+    }
+#undef lane
+#undef i
+#undef g
+}
+
+// ---- C ABI -------------------------------------------------------------------------------------------------------------------
+extern "C" size_t mbx_mlp_pack_bytes(int C, int hidden) { return (size_t)2 * C * hidden * sizeof(bf16_t); }
+
+extern "C" int mbx_mlp_pack_weights(const void* w1, const void* w2, void* packed, int C, int hidden, void* stream) {
+    MBX_CHECK_ARG(w1 && w2 && packed, "mlp_pack_weights: null pointer");
+    MBX_CHECK_ARG((C == 256 || C == 512) && hidden > 0 && hidden % F_CH == 0, "mlp_pack_weights: C=%d (256 or 512), hidden=%d (%% 64)", C, hidden);
+    const int nfrag = hidden / F_CH * (C / 4);
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3((nfrag + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w1, (const bf16_t*)w2,
+                       (bf16_t*)packed, C, hidden);
+    MBX_LAUNCH_CHECK("mlp_pack_weights");
+    return 0;
+}
+
+template <int C>
+static int launch_mlp_fused(const void* a, const void* packed, const float* b1, const float* b2, const float* rsum, int raw_in,
+                            const float* resid, float* y, void* yb, float eps, float* mean, float* rstd, int M, int hidden, hipStream_t s) {
+    const size_t shm = F_RING + (size_t)(2 * hidden + C) * sizeof(float) + (C == 512 ? 4 * 4096 : 0);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+        return mbx_set_error("mlp_fused_fwd: cannot reserve %zu bytes of LDS", shm);
+    hipLaunchKernelGGL(mlp_fused_kernel<C>, dim3((M + F_BM - 1) / F_BM), dim3(256), shm, s, (const bf16_t*)a, (const char*)packed, b1, b2,
+                       rsum, raw_in, resid, y, (bf16_t*)yb, eps, mean, rstd, M, hidden);
+    MBX_LAUNCH_CHECK("mlp_fused_fwd");
+    return 0;
+}
+
+extern "C" int mbx_mlp_fused_fwd(const void* a, int raw_in, const void* packed, const float* b1, const float* b2, const float* rsum,
+                                 const float* resid, float* y, void* y_t, float eps, float* mean, float* rstd, int M, int C,
+                                 int hidden, void* stream) {
+    MBX_CHECK_ARG(a && packed && b1 && b2 && resid && y, "mlp_fused_fwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && (C == 256 || C == 512) && hidden >= F_CH && hidden % F_CH == 0 && hidden <= 1536,
+                  "mlp_fused_fwd: bad shape M=%d C=%d (256 or 512) hidden=%d (%% 64, 64..1536)", M, C, hidden);
+    MBX_CHECK_ARG(!raw_in || rsum, "mlp_fused_fwd: a raw operand needs rsum (row sums of the folded fc1 weights)");
+    MBX_CHECK_ARG((mean && rstd) || (!mean && !rstd), "mlp_fused_fwd: mean and rstd come together");
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 512) return launch_mlp_fused<512>(a, packed, b1, b2, rsum, raw_in, resid, y, y_t, eps, mean, rstd, M, hidden, s);
+    return launch_mlp_fused<256>(a, packed, b1, b2, rsum, raw_in, resid, y, y_t, eps, mean, rstd, M, hidden, s);
+}

@@ -45,6 +45,11 @@ SIGNATURES = {
     'mbx_xcc_probe': (_i, [_vp, _i, _vp]),
     'mbx_unfold_norm_grads_ws': (_sz, [_i, _i]),
     'mbx_unfold_norm_grads': (_i, [_vp] * 7 + [_i, _i, _vp, _vp]),
+    'mbx_gemm_nt_resid_t': (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
+    'mbx_gemm_nt_rawln': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
+    'mbx_mlp_pack_bytes': (_sz, [_i, _i]),
+    'mbx_mlp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'mbx_mlp_fused_fwd': (_i, [_vp, _i] + [_vp] * 7 + [_f, _vp, _vp, _i, _i, _i, _vp]),
     'mbx_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),
     'mbx_split_bf16': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'mbx_gemm_nt_x3': (_i, [_vp] * 5 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),
@@ -251,6 +256,33 @@ class HipOps:
         M, K = a_t.shape
         N = w_t.shape[0]
         self._ck(self.lib.mbx_gemm_nt_lnbwd(_p(a_t), _p(w_t), _p(xhat), _p(rowc), _p(dres), _p(extra), _p(dx), _p(dx_t), M, N, K, self._stream()))
+
+    # ------------------------------------------------------------------ raw-operand LayerNorm + fused MLP (bf16 no-grad path)
+    @staticmethod
+    def can_fuse_mlp(tdtype, cfg) -> bool:
+        """The fused MLP forward (mbx_mlp_fused_fwd) and the raw-operand GEMMs exist for bf16, C in {256, 512}."""
+        return tdtype == torch.bfloat16 and cfg.C in (256, 512) and cfg.hidden % 64 == 0 and cfg.hidden <= 1536
+
+    def mlp_pack_weights(self, w1_t, w2_t):
+        """fc1 [hidden, C] and fc2 [C, hidden] (bf16) -> the MFMA-fragment stream mbx_mlp_fused_fwd consumes."""
+        hidden, Cc = w1_t.shape
+        packed = torch.empty(int(self.lib.mbx_mlp_pack_bytes(Cc, hidden)), dtype=torch.uint8, device=w1_t.device)
+        self._ck(self.lib.mbx_mlp_pack_weights(_p(w1_t), _p(w2_t), _p(packed), Cc, hidden, self._stream()))
+        return packed
+
+    def mlp_fused_fwd(self, a_t, raw_in, packed, b1, b2, rsum, resid, y, y_t, eps, mean, rstd):
+        M, Cc = a_t.shape
+        self._ck(self.lib.mbx_mlp_fused_fwd(_p(a_t), int(bool(raw_in)), _p(packed), _p(b1), _p(b2), _p(rsum), _p(resid), _p(y), _p(y_t),
+                                            float(eps), _p(mean), _p(rstd), M, Cc, b1.shape[0], self._stream()))
+
+    def gemm_nt_resid_t(self, a_t, w_t, bias, resid, y, y_t):
+        M, K = a_t.shape
+        self._ck(self.lib.mbx_gemm_nt_resid_t(_p(a_t), _p(w_t), _p(bias), _p(resid), _p(y), _p(y_t), M, w_t.shape[0], K, self._stream()))
+
+    def gemm_nt_rawln(self, a_t, w_t, bias, rsum, mean, rstd, out_t):
+        M, K = a_t.shape
+        self._ck(self.lib.mbx_gemm_nt_rawln(_p(a_t), _p(w_t), _p(bias), _p(rsum), _p(mean), _p(rstd), _p(out_t), M, w_t.shape[0], K,
+                                            self._stream()))
 
     # ------------------------------------------------------------------ residual GEMM + the next LayerNorm (bf16 path)
     def can_fuse_resid_ln(self, tdtype, N: int, device=None) -> bool:

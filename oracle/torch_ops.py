@@ -213,6 +213,55 @@ class MockOps:
         xhat = (y - mu[:, None]) * rs[:, None]
         xn.copy_((xhat if gamma is None else xhat * gamma + beta).to(xn.dtype))
 
+    # LayerNorm as a raw operand + the fused MLP forward (include/mbx.h; the no-grad path) ---------------------
+    fuse_mlp = True           # tests switch it off to exercise the unfused no-grad sequencing
+
+    def can_fuse_mlp(self, tdtype, cfg):
+        return bool(self.fuse_mlp) and cfg.hidden % 64 == 0
+
+    def mlp_pack_weights(self, w1_t, w2_t):
+        """The HIP library reorders the two weights into MFMA-fragment order; the restatement keeps them as they are."""
+        self._log('mlp_pack_weights')
+        return (w1_t, w2_t)
+
+    def mlp_fused_fwd(self, a_t, raw_in, packed, b1, b2, rsum, resid, y, y_t, eps, mean, rstd):
+        """y = resid + fc2(gelu(fc1)), fc1 = a . W1^T + b1 (raw_in = 0: a is the normalised operand) or
+        rstd_a (a . W1^T - mean_a rsum) + b1 with (mean_a, rstd_a) the statistics of the bf16 rows of a (raw_in = 1);
+        the hidden passes through the operand type once (the kernel packs gelu(.) to bf16 for the second MFMA);
+        y_t = T(y); mean / rstd = LayerNorm statistics of the rows of y."""
+        self._log('mlp_fused_fwd')
+        w1_t, w2_t = packed
+        af = a_t.float()
+        acc = af @ w1_t.float().t()
+        if raw_in:
+            mu = af.mean(-1, keepdim=True)
+            rs = torch.rsqrt(((af * af).mean(-1, keepdim=True) - mu * mu).clamp_min(0) + eps)
+            u = rs * (acc - mu * rsum) + b1
+        else:
+            u = acc + b1
+        gact = F.gelu(u).to(a_t.dtype)
+        out = resid + gact.float() @ w2_t.float().t() + b2
+        y.copy_(out)
+        if y_t is not None:
+            y_t.copy_(out.to(y_t.dtype))
+        if mean is not None:
+            mu_y = out.mean(-1)
+            mean.copy_(mu_y)
+            rstd.copy_(torch.rsqrt(((out - mu_y[:, None]) ** 2).mean(-1) + eps))
+
+    def gemm_nt_resid_t(self, a_t, w_t, bias, resid, y, y_t):
+        """MBX_EPI_RESID + y_t = T(y)."""
+        self._log('gemm_nt.resid_t')
+        out = resid + a_t.float() @ w_t.float().t() + (bias if bias is not None else 0.0)
+        y.copy_(out)
+        y_t.copy_(out.to(y_t.dtype))
+
+    def gemm_nt_rawln(self, a_t, w_t, bias, rsum, mean, rstd, out_t):
+        """out_t = rstd (a . w^T - mean rsum) + bias: the Linear behind a LayerNorm whose input rows arrive raw."""
+        self._log('gemm_nt.rawln')
+        acc = a_t.float() @ w_t.float().t()
+        out_t.copy_((rstd[:, None] * (acc - mean[:, None] * rsum) + bias).to(out_t.dtype))
+
     def gelu_fwd(self, u, g):
         self._log('gelu_fwd')
         g.copy_(F.gelu(u.float()).to(g.dtype))

@@ -1,0 +1,122 @@
+"""The no-grad path's kernels on a real MI355X against their torch restatement (oracle/torch_ops.MockOps, run on the GPU):
+the fused MLP forward (mbx_mlp_fused_fwd: LayerNorm'd or raw operand -> fc1 -> GELU -> fc2 -> + residual, reference
+lib/model/DSTformer.py:79-85 inside Block.forward :241-249), the residual GEMM that also leaves bf16(y) (mbx_gemm_nt_resid_t) and
+the Linear that applies the LayerNorm row constants in its epilogue (mbx_gemm_nt_rawln).
+
+Tolerances (relative L2): fp32 outputs of a bf16 GEMM chain 2e-5 where the operands are identical; the MLP's y goes through ONE
+bf16 rounding of the hidden in both implementations (a value that lands on the other side of a rounding boundary differs by
+2^-8): branch alone 1e-3, y 2e-4; bf16 outputs 4e-3; statistics 2e-5."""
+import pytest
+import torch
+
+from tests.mock_ops import MockOps
+from tests.test_gpu_kernels import DEV, check, rnd
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from motionbert_amd import hip_ops
+    return hip_ops.get()
+
+
+def _mlp_case(ops, M, C, hidden, raw_in, want_t, want_stats, seed=0):
+    eps = 1e-6
+    if raw_in:      # rows with a mean of their own and unequal scales: what a residual stream looks like
+        x = rnd(M, C, seed=seed + 1) * (0.5 + rnd(M, 1, seed=seed + 7).abs()) + 0.7 * rnd(M, 1, seed=seed + 8)
+        a = x.to(BF)
+    else:
+        x = rnd(M, C, seed=seed + 1)
+        a = ((x - x.mean(-1, keepdim=True)) * torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + eps)).to(BF)
+    w1, w2 = rnd(hidden, C, seed=seed + 2, dtype=BF, scale=0.06), rnd(C, hidden, seed=seed + 3, dtype=BF, scale=0.04)
+    b1, b2 = rnd(hidden, seed=seed + 4, scale=0.3), rnd(C, seed=seed + 5, scale=0.3)
+    rsum = w1.float().sum(1)
+    packed = ops.mlp_pack_weights(w1, w2)
+    mk = lambda *s, dt=torch.float32: torch.full(s, float('nan'), device=DEV, dtype=dt)
+    y, y2 = mk(M, C), mk(M, C)
+    yt, yt2 = (mk(M, C, dt=BF), mk(M, C, dt=BF)) if want_t else (None, None)
+    (mean, rstd, mean2, rstd2) = (mk(M), mk(M), mk(M), mk(M)) if want_stats else (None,) * 4
+    ops.mlp_fused_fwd(a, raw_in, packed, b1, b2, rsum if raw_in else None, x, y, yt, eps, mean, rstd)
+    MockOps().mlp_fused_fwd(a, raw_in, (w1, w2), b1, b2, rsum, x, y2, yt2, eps, mean2, rstd2)
+    tag = f'C{C}.h{hidden}.M{M}.raw{int(raw_in)}'
+    check(f'mlp_fused.branch.{tag}', y - x, y2 - x, 1e-3)
+    check(f'mlp_fused.y.{tag}', y, y2, 2e-4)
+    if want_t:
+        check(f'mlp_fused.y_t.{tag}', yt, yt2, 4e-3)
+    if want_stats:      # the statistics of the rows the kernel itself wrote (fp64 from its y), and those of the restatement
+        yd = y.double()
+        mu = yd.mean(-1)
+        rs = torch.rsqrt(((yd - mu[:, None]) ** 2).mean(-1) + eps)
+        scale = float(yd.std())
+        assert float((mean.double() - mu).abs().max()) < 2e-6 * max(scale, 1.0), f'mlp_fused.mean.{tag}'
+        check(f'mlp_fused.rstd.{tag}', rstd, rs.float(), 2e-6)
+        check(f'mlp_fused.rstd_vs_restatement.{tag}', rstd, rstd2, 1e-4)
+    return a, packed, b1, b2, rsum, x, y
+
+
+@pytest.mark.parametrize('raw_in', [0, 1])
+@pytest.mark.parametrize('M,C,hidden', [(128, 512, 1024), (4131, 512, 1024), (70227, 512, 1024), (2754, 256, 1024), (389, 256, 128),
+                                        (389, 512, 64), (1, 512, 1024), (129, 256, 1024)])
+def test_mlp_fused_fwd(ops, M, C, hidden, raw_in):
+    _mlp_case(ops, M, C, hidden, raw_in, True, True)
+
+
+def test_mlp_fused_fwd_optional_outputs_and_inplace(ops):
+    """y_t / statistics are optional; y may alias the residual input (each element is read before it is written, by the same lane)."""
+    M, C, hidden = 4131, 512, 1024
+    a, packed, b1, b2, rsum, x, y = _mlp_case(ops, M, C, hidden, 1, False, False, seed=20)
+    x2 = x.clone()
+    ops.mlp_fused_fwd(a, 1, packed, b1, b2, rsum, x2, x2, None, 1e-6, None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(x2, y)
+    # bit-for-bit repeatable (no atomics, no order-dependent reductions)
+    y3 = torch.empty_like(y)
+    ops.mlp_fused_fwd(a, 1, packed, b1, b2, rsum, x, y3, None, 1e-6, None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(y3, y)
+
+
+def test_mlp_fused_matches_unfused_kernels(ops):
+    """Against the kernel pair it replaces (mbx_gemm_nt GELU + RESID on the same operands): same bf16 operands, same fp32
+    accumulation, the GELU polynomial of the same header -- only summation order differs."""
+    from motionbert_amd.engine import EPI_GELU, EPI_RESID
+    M, C, hidden = 70227, 512, 1024
+    a, packed, b1, b2, rsum, x, y = _mlp_case(ops, M, C, hidden, 0, False, False, seed=30)
+    w1, w2 = rnd(hidden, C, seed=32, dtype=BF, scale=0.06), rnd(C, hidden, seed=33, dtype=BF, scale=0.04)
+    g = torch.empty(M, hidden, device=DEV, dtype=BF)
+    ops.gemm_nt(a, w1, b1, EPI_GELU, out_t=None, out2_t=g)
+    y2 = torch.empty(M, C, device=DEV)
+    ops.gemm_nt(g, w2, b2, EPI_RESID, out_f=y2, resid=x)
+    check('mlp_fused.vs_unfused.branch', y - x, y2 - x, 1e-3)
+    check('mlp_fused.vs_unfused.y', y, y2, 2e-4)
+
+
+@pytest.mark.parametrize('M,N,K', [(306, 512, 512), (4131, 512, 512), (70227, 512, 1024), (2754, 256, 256)])
+def test_gemm_nt_resid_t(ops, M, N, K):
+    a, w, bias, resid = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, dtype=BF, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
+    y, y2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    yt, yt2 = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt_resid_t(a, w, bias, resid, y, yt)
+    MockOps().gemm_nt_resid_t(a, w, bias, resid, y2, yt2)
+    check(f'gemm_nt_resid_t.y.{M}x{N}x{K}', y, y2, 2e-5)
+    check(f'gemm_nt_resid_t.y_t.{M}x{N}x{K}', yt, yt2, 4e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(yt, y.to(BF)), 'y_t must be the rounding of the y this launch wrote'
+
+
+@pytest.mark.parametrize('M,N,K', [(306, 768, 256), (4131, 1536, 512), (70227, 1536, 512), (300, 256, 512)])
+def test_gemm_nt_rawln(ops, M, N, K):
+    yrow = rnd(M, K, seed=1) * (0.5 + rnd(M, 1, seed=7).abs()) + 0.7 * rnd(M, 1, seed=8)
+    a, w, bias = yrow.to(BF), rnd(N, K, seed=2, dtype=BF, scale=0.05), rnd(N, seed=3)
+    rsum = w.float().sum(1)
+    mean = yrow.mean(-1)
+    rstd = torch.rsqrt(yrow.var(-1, unbiased=False) + 1e-6)
+    out, ref = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt_rawln(a, w, bias, rsum, mean, rstd, out)
+    MockOps().gemm_nt_rawln(a, w, bias, rsum, mean, rstd, ref)
+    check(f'gemm_nt_rawln.{M}x{N}x{K}', out, ref, 4e-3)
+    # and it is the Linear behind the LayerNorm: against LayerNorm(y) . w^T + bias taken in fp32 from the fp32 rows
+    exact = ((yrow - mean[:, None]) * rstd[:, None]) @ w.float().t() + bias
+    check(f'gemm_nt_rawln.vs_layernorm.{M}x{N}x{K}', out, exact, 1e-2)

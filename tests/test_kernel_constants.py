@@ -1,4 +1,4 @@
-"""The polynomial constants of the packed GELU / GELU' epilogues (motionbert_amd/csrc/gemm_pipe.hip: gelu_fast2, gelu_fast_grad2),
+"""The polynomial constants of the packed GELU / GELU' epilogues (motionbert_amd/csrc/gelu_fast.h: gelu_fast2, gelu_fast_grad2),
 read from the kernel source and evaluated here in float32 exactly as the kernel does: a typo in one literal would still pass the
 bf16-tolerance kernel tests for most inputs, this pins the fp32 error of the formulas themselves (nn.GELU = erf form,
 reference lib/model/DSTformer.py:79-85)."""
@@ -9,7 +9,7 @@ import numpy as np
 from scipy.special import erf
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = open(os.path.join(ROOT, 'motionbert_amd', 'csrc', 'gemm_pipe.hip')).read()
+SRC = open(os.path.join(ROOT, 'motionbert_amd', 'csrc', 'gelu_fast.h')).read()
 F32 = np.float32
 
 
