@@ -276,6 +276,11 @@ def bench_block(dev, B=256, T=243, iters=5):
     eng.grads = {n: torch.empty_like(p) for n, p in P.items() if n.startswith(pre + '.')}
 
     def fwd(need_grad):
+        # the forward-only pass is the engine's no-grad sequencing (raw-operand LayerNorm + fused MLP) when the provider has it
+        raw = (not need_grad) and eng.fold and eng.rawln_allowed and ops.can_fuse_mlp(eng.T, cfg)
+        if raw != eng.rawln:
+            eng.rawln = raw
+            eng.prepare_weights(need_grad)
         return eng._block_fwd(h, pre, 'st', need_grad)
 
     def fwd_bwd():

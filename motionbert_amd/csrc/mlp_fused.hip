@@ -20,7 +20,8 @@
 //     ends up holding hidden columns {8q + 4g + e} of token i, i.e. eight of the sixteen k-slots of two K = 16 steps, as long as
 //     W2's fragments list the hidden index in the same permuted order -- which the weight packer guarantees;
 //   * acc2[32 x C] += G . W2c^T (C/32 x 4 MFMAs), C/2 accumulator registers that live across all chunks;
-//   * epilogue: + bias + residual -> y (fp32) and bf16(y), mean / rstd over the wave's complete rows.
+//     -- they START from residual + bias (loaded in the prologue), so the MFMAs leave y itself;
+//   * epilogue: write y (fp32) and bf16(y), mean / rstd over the wave's complete rows.
 // Register file (C = 512): acc2 256 + X 128 = 384 registers in the ACCUMULATOR half of the unified file (MFMA reads X from there
 // as its B operand), 128 VGPRs for acc1 (32), two generations of the packed hidden (32), eight weight fragments in flight (32) and
 // the GELU arithmetic.  hipcc cannot be talked into that split (its allocation of the plain-builtin version spills and shuffles
@@ -53,13 +54,30 @@ __device__ __forceinline__ void glds16(const void* src, const void* lds_dst) {
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 #define GLDS16(src, dst) glds16((src), (dst))
+// The weight stream's form: wave-uniform 64-bit base in SGPRs + this lane's constant 32-bit byte offset in a VGPR (no per-piece
+// vector address arithmetic), M0 written but not restored -- nothing the compiler emits in this kernel reads M0 (gfx9+ LDS
+// instructions do not), and every DMA statement sets it itself.
+__device__ __forceinline__ void glds16_s(const char* base, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+// 16 bytes from LDS at a byte address kept in a register the compiler cannot fold a constant into (so the fragment reads of a stage
+// are `ds_read_b128 v, base offset:imm`: one address register per stage instead of one v_add per read)
+typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // one MFMA operand fragment (8 bf16)
+__device__ __forceinline__ u32x4_t lds_read16(unsigned base, int imm) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(base + imm);
+}
 
+// Ablation switches of diagnostic builds (tools/build_variants.py name -DMBX_MLP_DBG=bits; results are wrong, timing only):
+// 1 no GELU micro-steps beside fc2, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no epilogue, 16 no MFMAs, 32 no barriers,
+// 64 no stages at all (prologue + epilogue only)
+#ifndef MBX_MLP_DBG
+#define MBX_MLP_DBG 0
+#endif
 static constexpr int F_BM = 128;               // token rows per workgroup (4 waves x 32)
 static constexpr int F_STAGE = 32 * 1024;      // one ring stage = 32 fragments of 1 KiB
 static constexpr int F_RING = 4 * F_STAGE;     // 128 KiB
 static constexpr int F_CH = 64;                // hidden columns per chunk
-
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // one MFMA operand fragment (8 bf16)
 
 // ---- packed weight stream ---------------------------------------------------------------------------------------------------
 // chunk c (hidden columns [64 c, 64 c + 64)) = C/4 fragments: first the fc1 part, fragment (s, tn) at index 2 s + tn
@@ -102,10 +120,9 @@ __device__ __forceinline__ float2 ge_bias_ld(const char* p) {
 
 // MFMA statements.  D = A(weights fragment, VGPR) x B(token fragment) + C.  fc1: accumulator in VGPRs (the GELU reads it), token
 // operand X in accumulator registers; fc2: accumulator in accumulator registers, token operand = the packed hidden (VGPR).
-// The *_Z forms start a chain from zero (no register initialisation, hence no write -> MFMA wait state to own).
+// MFMA_FC1_Z starts a chain from zero (no register initialisation, hence no write -> MFMA wait state to own).
 #define MFMA_FC1_Z(acc_, w_, x_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc_) : "v"(w_), "v"(x_))
 #define MFMA_FC1(acc_, w_, x_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc_) : "v"(w_), "v"(x_))
-#define MFMA_FC2_Z(acc_, w_, g_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc_) : "v"(w_), "v"(g_))
 #define MFMA_FC2(acc_, w_, g_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc_) : "v"(w_), "v"(g_))
 // wait states between the last MFMA that writes a register and its first non-MFMA reader / writer (8-pass XDL: 12; 16 taken)
 #define MFMA_PAD_V(a_, b_) asm volatile("s_nop 15" : "+v"(a_), "+v"(b_))
@@ -126,7 +143,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     constexpr int GSTEPS = 2 / S2;         // GELU micro-steps per fc2 slot (64 per chunk over S2 * 32 slots)
     constexpr int XL = C == 512 ? 4 : 0;   // the last XL fragments of X are kept in LDS and visit registers only around their use (the
                                            // second fc1 stage): the GELU stages, where every VGPR is spoken for, do not carry them
-    constexpr int PF = 5;                  // weight fragments in flight ahead of the MFMA that consumes them
+#ifndef MBX_MLP_PF
+#define MBX_MLP_PF 5
+#endif
+    constexpr int PF = MBX_MLP_PF;         // weight fragments in flight ahead of the MFMA that consumes them (<= 7)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ring 128 KiB | b1 [hidden] | rsum [hidden] | b2 [C] | XL KiB per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
@@ -138,6 +158,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     char* const xsp = reinterpret_cast<char*>(b2s + C) + wave * (XL * 1024) + lane * 16;
     const int nch = hidden / F_CH, NS = nch * 2 * S2;
 
+    // (Measured and dropped, round 4: a start stagger of the first workgroup of every CU by k/8 of a tile period, to run the memory
+    // phases of some CUs under the compute phases of the others -- 101.2 us per tile round with and 102.7-103.3 without, i.e. null:
+    // the CUs are not phase-locked.  Prologue-only and epilogue-only builds run at 4.8 / 5.4 TB/s = ~11 B/clk per CU, the per-CU
+    // miss-bandwidth limit, and that time ADDS to the loop's: profiles/r04_mlp_fused_ablation.txt.)
     for (int k = tid; k < hidden; k += 256) { b1s[k] = b1[k]; rss[k] = raw_in ? rsum[k] : 0.f; }
     for (int k = tid; k < C; k += 256) b2s[k] = b2[k];
 
@@ -181,7 +205,37 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
 #pragma unroll
     for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                  // every wave has its X; the biases are in LDS; the ring is free
+    __builtin_amdgcn_s_barrier();                  // the biases are in LDS
+
+    // ---- the fc2 accumulators start from residual + bias: y = x + b2 + G . W2^T is then what the MFMAs leave, and the epilogue
+    // only writes.  Per 256-column half the wave's 32 residual rows arrive in its LDS image by LDS-DMA (one instruction = one row's
+    // KiB; 16-byte piece p of row r at p ^ (r & 15), applied to the source address: conflict-free both in the accumulator layout --
+    // lane (i, g): row i, piece 8 ntl + 2 qq + g -- and row-major), and each lane takes its accumulator registers from it.
+    f32x16_t acc2[NT2];
+    char* const er = ring + wave * 32768;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the image's previous readers (X fragments / first half) are done
+#pragma unroll 4
+        for (int r = 0; r < 32; ++r)
+            GLDS16(resid + (size_t)min(mw + r, M - 1) * C + hh * 256 + ((lane ^ (r & 15)) << 2), er + r * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ntl = 0; ntl < 8; ++ntl) {
+            const int nt = hh * 8 + ntl;
+            f32x16_t t;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const float4 bb = *reinterpret_cast<const float4*>(b2s + nt * 32 + 8 * qq + 4 * g);
+                const float4 xv = *reinterpret_cast<const float4*>(er + i * 1024 + (((ntl * 8 + 2 * qq + g) ^ (i & 15)) << 4));
+                t[4 * qq] = xv.x + bb.x; t[4 * qq + 1] = xv.y + bb.y; t[4 * qq + 2] = xv.z + bb.z; t[4 * qq + 3] = xv.w + bb.w;
+            }
+            acc2[nt] = t;
+            asm volatile("s_nop 1" : "+a"(acc2[nt]));             // a whole tile at a time into accumulator registers, where it stays
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // every wave is done with its image: the ring is free
 
     // ---- weight stream -------------------------------------------------------------------------------------------------------
     // stage sequence q -> byte offset in the packed stream:  A(0) | A(1) B(0) | A(2) B(1) | ... | A(n-1) B(n-2) | B(n-1)
@@ -192,9 +246,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         const int last = (nch - 1) * CHB + (S2 + r) * F_STAGE;
         return qc < S2 ? qc * F_STAGE : (grp >= nch - 1 ? last : mid);
     };
-    const char* const wl = wpk + wave * 1024 + lane * 16;       // this lane's 16 bytes of piece d (fragments 4 d + wave) of a stage
-    char* const dl = ring + wave * 1024;
-#define MF_ISSUE1(src_, slot_, d_) GLDS16((src_) + (d_) * 4096, dl + (slot_) * F_STAGE + (d_) * 4096)
+    // piece d of a stage = its fragments 4 d .. 4 d + 3, one per wave: this lane's 16 bytes sit at stage + 4096 d + 1024 wave + 16 lane
+    const unsigned wvo = wave * 1024 + lane * 16;
+    const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
+#define MF_ISSUE1(src_, slot_, d_) glds16_s((src_) + (d_) * 4096, wvo, dl + (slot_) * F_STAGE + (d_) * 4096)
     // stage q + 1 has landed (this wave's pieces: counted wait; everyone's: barrier) and everyone is done with stage q - 1
 #define MF_SYNC(n_)                                                                                                  \
     do {                                                                                                             \
@@ -204,20 +259,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     } while (0)
 
-    f32x16_t acc2[NT2];
     f32x16_t acc1[2];
     // packed hidden: the fc2 of chunk c - 1 reads G[0..3] in order while the GELU of chunk c produces its four fragments in order;
     // fragment n + 1 of the new generation goes into the registers of fragment n of the old one (dead by then), fragment 0 into G[4]
     u32x4_t G[5];
     u32x4_t fb[8];                                              // weight fragments: slot k of a stage lives in fb[k & 7] (PF + 1 of them alive)
     u32x4_t xl[XL > 0 ? XL : 1];                                // the LDS-resident fragments of X, in registers during the second fc1 stage only
-    const char* const fr = ring + lane * 16;                    // fragment f of ring slot s: fr + s * F_STAGE + f * 1024
+    const unsigned fr = (unsigned)(uintptr_t)(const lds_void_t*)ring + lane * 16;   // fragment f of ring slot s: fr + s * F_STAGE + f * 1024
 
     int q = 0;                                                  // stage sequence number
     {
-        const char* const s0 = wl + seq_off(0);
-        const char* const s1 = wl + seq_off(1);
-        const char* const s2 = wl + seq_off(2);
+        const char* const s0 = wpk + seq_off(0);
+        const char* const s1 = wpk + seq_off(1);
+        const char* const s2 = wpk + seq_off(2);
 #pragma unroll
         for (int d = 0; d < 8; ++d) MF_ISSUE1(s0, 0, d);
 #pragma unroll
@@ -227,24 +281,25 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     }
     MF_SYNC(10);                                                // stage 0 is in LDS
 #pragma unroll
-    for (int k = 0; k < PF; ++k) fb[k] = *reinterpret_cast<const u32x4_t*>(fr + k * 1024);
+    for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
 
     // One stage = 32 slots.  Slot k: read the fragment of slot k + PF (from slot 32 - PF on, a fragment of the NEXT stage: the
     // barrier sits in front of slot 24), one MFMA, every fourth slot one LDS-DMA piece (slots 3..23: pieces 2..7 of stage q + 2,
     // slots 27, 31: pieces 0, 1 of stage q + 3), then HOOK_ (GELU micro-steps); sched_barrier(0) pins the slot.
 #define MF_STAGE(MMA_, HOOK_)                                                                                        \
-    do {                                                                                                             \
-        const char* const st_ = fr + (q & 3) * F_STAGE;                                                              \
-        const char* const sn_ = fr + ((q + 1) & 3) * F_STAGE;                                                        \
-        const char* const n2_ = wl + seq_off(q + 2);                                                                 \
-        const char* const n3_ = wl + seq_off(q + 3);                                                                 \
+    if (!(MBX_MLP_DBG & 64)) do {                                                                                    \
+        unsigned st_ = fr + (q & 3) * F_STAGE, sn_ = fr + ((q + 1) & 3) * F_STAGE;                                   \
+        asm volatile("" : "+v"(st_), "+v"(sn_));                                                                     \
+        const char* const n2_ = wpk + seq_off(q + 2);                                                                \
+        const char* const n3_ = wpk + seq_off(q + 3);                                                                \
         const int l2_ = (q + 2) & 3, l3_ = (q + 3) & 3;                                                              \
         _Pragma("unroll") for (int k_ = 0; k_ < 32; ++k_) {                                                          \
-            if (k_ == 24) MF_SYNC(8);                                                                                \
-            fb[(k_ + PF) & 7] = *reinterpret_cast<const u32x4_t*>(k_ + PF < 32 ? st_ + (k_ + PF) * 1024 : sn_ + (k_ + PF - 32) * 1024); \
-            MMA_(k_, fb[k_ & 7]);                                                                                    \
-            if ((k_ & 3) == 3) { if (k_ < 24) MF_ISSUE1(n2_, l2_, (k_ >> 2) + 2); else MF_ISSUE1(n3_, l3_, (k_ >> 2) - 6); } \
-            HOOK_(k_);                                                                                               \
+            if (k_ == 24 && !(MBX_MLP_DBG & 32)) MF_SYNC(8);                                                         \
+            if (!(MBX_MLP_DBG & 4))                                                                                  \
+                fb[(k_ + PF) & 7] = k_ + PF < 32 ? lds_read16(st_, (k_ + PF) * 1024) : lds_read16(sn_, (k_ + PF - 32) * 1024); \
+            if (!(MBX_MLP_DBG & 16) || (k_ & 15) == 0) MMA_(k_, fb[k_ & 7]);                                         \
+            if ((k_ & 3) == 3 && !(MBX_MLP_DBG & 2)) { if (k_ < 24) MF_ISSUE1(n2_, l2_, (k_ >> 2) + 2); else MF_ISSUE1(n3_, l3_, (k_ >> 2) - 6); } \
+            if (!(MBX_MLP_DBG & 1)) HOOK_(k_);                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
         ++q;                                                                                                         \
@@ -259,6 +314,34 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
 #define GE_BIAS(j_) ge_bias_ld(smem + F_RING + 16 * g + (gc * F_CH + ((j_) >> 3) * 32 + 8 * (((j_) >> 1) & 3) + 2 * ((j_) & 1)) * 4)
 #define GE_RSUM(j_) ge_bias_ld(smem + F_RING + 4 * hidden + 16 * g + (gc * F_CH + ((j_) >> 3) * 32 + 8 * (((j_) >> 1) & 3) + 2 * ((j_) & 1)) * 4)
 #define GE_LOAD(j_) do { ge_b = GE_BIAS(j_); ge_r = GE_RSUM(j_); } while (0)
+#ifndef MBX_MLP_GELU_SCALAR
+#define MBX_MLP_GELU_SCALAR 0
+#endif
+#if MBX_MLP_GELU_SCALAR      // A/B form: the same arithmetic on scalar fp32 operations (two interleaved chains, no packed instructions)
+    float gu0, gu1, ga0, ga1, gd0, gd1;
+#define GE_STEP(ms_)                                                                                                 \
+    do {                                                                                                             \
+        const int j_ = (ms_) >> 2, st_ = (ms_) & 3, tn_ = j_ >> 3, qq_ = (j_ >> 1) & 3, r0_ = 4 * qq_ + 2 * (j_ & 1);  /* fold after unrolling */ \
+        if (st_ == 0) {                                                                                              \
+            gu0 = fmaf(ln_rs, acc1[tn_][r0_], fmaf(ln_k, ge_r.x, ge_b.x)); gu1 = fmaf(ln_rs, acc1[tn_][r0_ + 1], fmaf(ln_k, ge_r.y, ge_b.y)); \
+            if (j_ + 1 < 16) GE_LOAD(j_ + 1);                                                                        \
+            ga0 = fabsf(gu0); ga1 = fabsf(gu1);                                                                      \
+            gd0 = fmaf(ga0, 5.382975e-06f, 4.8890636e-05f); gd1 = fmaf(ga1, 5.382975e-06f, 4.8890636e-05f);          \
+            gd0 = fmaf(gd0, ga0, 3.8003575e-05f); gd1 = fmaf(gd1, ga1, 3.8003575e-05f);                              \
+            gd0 = fmaf(gd0, ga0, 3.2776264e-03f); gd1 = fmaf(gd1, ga1, 3.2776264e-03f);                              \
+        } else if (st_ == 1) {                                                                                       \
+            gd0 = fmaf(gd0, ga0, 2.1141006e-02f); gd1 = fmaf(gd1, ga1, 2.1141006e-02f);                              \
+            gd0 = fmaf(gd0, ga0, 4.9867347e-02f); gd1 = fmaf(gd1, ga1, 4.9867347e-02f);                              \
+            gd0 = fmaf(gd0, ga0, 1.0f); gd1 = fmaf(gd1, ga1, 1.0f);                                                  \
+            gd0 = __builtin_amdgcn_rcpf(gd0); gd1 = __builtin_amdgcn_rcpf(gd1);                                      \
+        } else if (st_ == 2) {                                                                                       \
+            gd0 *= gd0; gd1 *= gd1; gd0 *= gd0; gd1 *= gd1; gd0 *= gd0; gd1 *= gd1; gd0 *= gd0; gd1 *= gd1;          \
+        } else {                                                                                                     \
+            const float o0_ = ((gu0 + ga0) - ga0 * gd0) * 0.5f, o1_ = ((gu1 + ga1) - ga1 * gd1) * 0.5f;              \
+            G[(tn_ * 2 + (qq_ >> 1) + 4) % 5][2 * (qq_ & 1) + (j_ & 1)] = pack_bf2(o0_, o1_);                        \
+        }                                                                                                            \
+    } while (0)
+#else
 #define GE_STEP(ms_)                                                                                                 \
     do {                                                                                                             \
         const int j_ = (ms_) >> 2, st_ = (ms_) & 3, tn_ = j_ >> 3, qq_ = (j_ >> 1) & 3, r0_ = 4 * qq_ + 2 * (j_ & 1);  /* fold after unrolling */ \
@@ -281,6 +364,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             G[(tn_ * 2 + (qq_ >> 1) + 4) % 5][2 * (qq_ & 1) + (j_ & 1)] = pack_bf2(o_[0], o_[1]);                             \
         }                                                                                                            \
     } while (0)
+#endif
 
     // fc1 slot k of the stage's half h: k-step s = 16 h + (k >> 1), column half tn = k & 1
 #define MMA_A0(k_, w_) do { if ((k_) < 2) MFMA_FC1_Z(acc1[(k_) & 1], w_, X[(k_) >> 1]); else MFMA_FC1(acc1[(k_) & 1], w_, X[(k_) >> 1]); } while (0)
@@ -289,7 +373,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
 #define HOOK_A1(k_) do { if (XL > 0 && (k_) >= 16 && (k_) < 16 + 2 * XL && !((k_) & 1)) xl[((k_) - 16) >> 1] = *reinterpret_cast<const u32x4_t*>(xsp + (((k_) - 16) >> 1) * 1024); } while (0)
 #define HOOK_NONE(k_) do { } while (0)
     // fc2 slot k of the stage's part hb: k-step kk = hb KKS + k / NT2, output tile nt = k % NT2
-#define MMA_B0F(k_, w_) do { if ((k_) < NT2) MFMA_FC2_Z(acc2[(k_) % NT2], w_, G[(k_) / NT2]); else MFMA_FC2(acc2[(k_) % NT2], w_, G[(k_) / NT2]); } while (0)
 #define MMA_B0(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, G[(k_) / NT2])
 #define MMA_B1(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, G[KKS + (k_) / NT2])
     // GELU micro-steps beside fc2 slot k of part hb (C = 512: one per slot; C = 256: two); the first slot also pads the fc1 chain
@@ -313,101 +396,77 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                         G[3] = G[2]; G[2] = G[1]; G[1] = G[0]; G[0] = G[4];                                                         \
                         asm volatile("s_nop 3" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3])); } while (0)
     G_ROTATE();
-    if (nch > 1) {
-        // chunk 1: A(1), then B(0) (which starts the fc2 accumulators) || gelu(1)
-        MF_PART_A();
-        gc = 1;
+    for (int c = 1; c < nch; ++c) {
+        MF_PART_A();                       // A(c)
+        gc = c;
         GE_LOAD(0);
-        MF_STAGE(MMA_B0F, HOOK_G0);
+        MF_STAGE(MMA_B0, HOOK_G0);         // B(c - 1) || gelu(c)
         if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_G1);
         G_ROTATE();
-        for (int c = 2; c < nch; ++c) {
-            MF_PART_A();                   // A(c)
-            gc = c;
-            GE_LOAD(0);
-            MF_STAGE(MMA_B0, HOOK_G0);     // B(c - 1) || gelu(c)
-            if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_G1);
-            G_ROTATE();
-        }
-        MF_STAGE(MMA_B0, HOOK_NONE);       // B(n - 1)
-        if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_NONE);
-    } else {
-        MF_STAGE(MMA_B0F, HOOK_NONE);
-        if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_NONE);
     }
+    MF_STAGE(MMA_B0, HOOK_NONE);           // B(n - 1)
+    if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_NONE);
 
-    // ---- epilogue: y = acc2 + b2 + x -> y (fp32), bf16(y), (mean, rstd) of the row ------------------------------------------
+    // ---- epilogue: the accumulators hold y.  Statistics per lane (= half a row) as shifted sums, the halves joined by Chan's
+    // formula; then per 256-column half the accumulators go through the wave's LDS image and leave row-major: one instruction =
+    // one row's KiB of y / 512 B of bf16(y).  The accumulators are only READ (arithmetic on them would make new 16-register values).
+    if (MBX_MLP_DBG & 8) return;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-read tail stages have landed, the last prefetches returned
     __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring
 #pragma unroll
     for (int t = 0; t < NT2; ++t) MFMA_PAD_A(acc2[t]);
-    // The accumulators are only READ here (any arithmetic ON them makes new 16-register values and spills).  Per 256-column half:
-    // the wave's 32 residual rows arrive in a wave-private LDS image by LDS-DMA (32 rows x 1 KiB, 16-byte piece p of row r at
-    // p ^ (r & 15): conflict-free both in the accumulator layout -- lane (i, g): row i, piece 8 ntl + 2 qq + g -- and row-major);
-    // each lane adds its accumulator values IN PLACE, taking the row statistics on the way (shifted sums per lane = half a row,
-    // the halves joined by Chan's formula at the end); then the image is walked row-major: one instruction = one row's KiB of y /
-    // 512 B of bf16(y).  One wave's LDS operations execute in order, so the image needs no barriers.
     // (lane-derived values are re-derived from an opaque copy of the thread index: otherwise the compiler carries a dozen of them
     // through the main loop, where every VGPR is spoken for)
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
-    const int lane_e = tid_e & 63;
-#define lane lane_e
-    const int i_e = lane & 31, g_e = lane >> 5;
-#define i i_e
-#define g g_e
-    char* const er = ring + wave * 32768;
-    float sh = 0.f, s1 = 0.f, s2 = 0.f;
+    const int lane_e = tid_e & 63, i_e = lane_e & 31, g_e = lane_e >> 5;
     const int rows = min(32, M - mw);
+    // every accumulator tile is read ONCE: into the image, and (when the statistics are wanted) into the shifted sums on the way
+    const bool want_stats = mean_out != nullptr;
+    float sh = 0.f, s1 = 0.f, s2 = 0.f;
+    char* const eo = ring + wave * 32768;
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (second half: the row-major reads of the first one are done)
-#pragma unroll 4
-        for (int r = 0; r < 32; ++r)
-            GLDS16(resid + (size_t)min(mw + r, M - 1) * C + hh * 256 + ((lane ^ (r & 15)) << 2), er + r * 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ntl = 0; ntl < 8; ++ntl) {
             const int nt = hh * 8 + ntl;
+            const f32x16_t t = acc2[nt];
+            if (hh == 0 && ntl == 0) sh = t[0];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                float4* const pp = reinterpret_cast<float4*>(er + i * 1024 + (((ntl * 8 + 2 * qq + g) ^ (i & 15)) << 4));
-                const float4 bb = *reinterpret_cast<const float4*>(b2s + nt * 32 + 8 * qq + 4 * g);
-                const float4 xv = *pp;
-                const float v0 = acc2[nt][4 * qq] + bb.x + xv.x, v1 = acc2[nt][4 * qq + 1] + bb.y + xv.y;
-                const float v2 = acc2[nt][4 * qq + 2] + bb.z + xv.z, v3 = acc2[nt][4 * qq + 3] + bb.w + xv.w;
-                *pp = make_float4(v0, v1, v2, v3);
-                if (hh == 0 && ntl == 0 && qq == 0) sh = v0;
-                const float d0 = v0 - sh, d1 = v1 - sh, d2 = v2 - sh, d3 = v3 - sh;
-                s1 += (d0 + d1) + (d2 + d3);
-                s2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, s2))));
+                *reinterpret_cast<float4*>(eo + i_e * 1024 + (((ntl * 8 + 2 * qq + g_e) ^ (i_e & 15)) << 4)) =
+                    make_float4(t[4 * qq], t[4 * qq + 1], t[4 * qq + 2], t[4 * qq + 3]);
+                if (want_stats) {                                 // wave-uniform
+                    const float d0 = t[4 * qq] - sh, d1 = t[4 * qq + 1] - sh, d2 = t[4 * qq + 2] - sh, d3 = t[4 * qq + 3] - sh;
+                    s1 += (d0 + d1) + (d2 + d3);
+                    s2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, s2))));
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);                    // one tile's 16 registers at a time out of the accumulator file
         }
         float* const yrow = y + (size_t)mw * C + hh * 256;           // wave-uniform bases + a 32-bit lane offset
         bf16_t* const brow = yb_out + (size_t)mw * C + hh * 256;
 #pragma unroll 4
         for (int r = 0; r < rows; ++r) {
-            const float4 t = *reinterpret_cast<const float4*>(er + r * 1024 + ((lane ^ (r & 15)) << 4));
-            *reinterpret_cast<float4*>(yrow + (size_t)r * C + lane * 4) = t;
+            const float4 t = *reinterpret_cast<const float4*>(eo + r * 1024 + ((lane_e ^ (r & 15)) << 4));
+            *reinterpret_cast<float4*>(yrow + (size_t)r * C + lane_e * 4) = t;
             if (yb_out != nullptr)
-                *reinterpret_cast<uint2*>(brow + (size_t)r * C + lane * 4) = make_uint2(pack_bf2(t.x, t.y), pack_bf2(t.z, t.w));
+                *reinterpret_cast<uint2*>(brow + (size_t)r * C + lane_e * 4) = make_uint2(pack_bf2(t.x, t.y), pack_bf2(t.z, t.w));
         }
     }
-    if (mean_out != nullptr) {
+    if (want_stats) {
         constexpr float nh = (float)(C / 2);                          // values per lane
         const float mean_h = sh + s1 / nh, m2_h = s2 - s1 * s1 / nh;  // this half row: mean, sum of squared deviations
         const float mean_o = wave_halves<WaveAdd>(mean_h) - mean_h;   // the partner lane's half (lane ^ 32)
         const float m2_both = wave_halves<WaveAdd>(m2_h);
         const float delta = mean_o - mean_h;
         const float var = fmaxf((m2_both + delta * delta * (nh * 0.5f)) / (float)C, 0.f);
-        if (g == 0 && i < rows) {
-            mean_out[mw + i] = 0.5f * (mean_h + mean_o);
-            rstd_out[mw + i] = 1.0f / sqrtf(var + eps);
+        if (g_e == 0 && i_e < rows) {
+            mean_out[mw + i_e] = 0.5f * (mean_h + mean_o);
+            rstd_out[mw + i_e] = 1.0f / sqrtf(var + eps);
         }
     }
-#undef lane
-#undef i
-#undef g
 }
 
 // ---- C ABI -------------------------------------------------------------------------------------------------------------------

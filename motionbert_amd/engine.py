@@ -18,15 +18,19 @@ The temporal attention reads its (b, j, h) sequences straight out of the
 [B, T, J, 3C] qkv tensor with a row stride of J*3C elements: the three
 permute->contiguous copies of `DSTformer.py:190-192` do not exist here.
 
-What is saved for backward (per sub-layer): the fp32 sub-layer input, LN
-mean/rstd, the normalised T-typed GEMM input, and qkv/o/lse (attention) or
-the pre-/post-GELU hidden (MLP).  Attention probabilities are never stored:
-the backward kernels recompute them from q, k and lse.
+What is saved for backward (per sub-layer).  Folded sequencing (bf16 default): the plain normalisation xhat (T), rstd, and
+qkv / o / lse (attention) or the pre-/post-GELU hidden (MLP); the fp32 sub-layer input is NOT kept.  Plain sequencing (fp32-class
+modes, dropout): the fp32 input, LN mean / rstd, the normalised T-typed GEMM input and the same.  Attention probabilities are never
+stored: the backward kernels recompute them from q, k and lse.
+
+No-grad sequencing (bf16, `rawln`): nothing is saved, and inside a Block no LayerNorm pass and no hidden tensor exist -- the
+residual GEMM also leaves bf16(y), the MLP is ONE kernel (mbx_mlp_fused_fwd) that normalises its raw operand itself and leaves
+bf16(y) + (mean, rstd) of its output, and the qkv GEMM applies those row constants in its epilogue (mbx_gemm_nt_rawln).
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List, NamedTuple, Optional
 
 import os
 
@@ -41,6 +45,14 @@ EPI_DGELU = 4      # out_t  = acc * gelu'(aux_t)              (T)
 
 MODE_SPATIAL = 0
 MODE_TEMPORAL = 1
+
+
+class RawRows(NamedTuple):
+    """A residual-stream tensor handed to the LayerNorm -> Linear pair of the next sub-layer as a RAW operand (no-grad path):
+    t = bf16(y); mean / rstd = the LayerNorm statistics of the rows of y, or None when the consumer takes them itself."""
+    t: Any
+    mean: Any
+    rstd: Any
 
 
 @dataclass(frozen=True)
@@ -150,8 +162,13 @@ class Engine:
         # fp32-class modes (bf16 kernels only), or by request (model.fold_ln = False / MBX_FOLD_LN=0: the A/B switch).
         self.fold = (os.environ.get('MBX_FOLD_LN', '1') == '1' and not x3 and drop_seed is None and
                      bool(getattr(ops, 'can_fold', lambda *_: False)(tdtype, cfg)))
+        self.fold_dx_first = os.environ.get('MBX_FOLD_ORDER', '0') == '1'
         self.Bf: Dict[str, torch.Tensor] = {}
         self.Rs: Dict[str, torch.Tensor] = {}
+        # no-grad sequencing of a Block (decided per forward): raw-operand LayerNorm + fused MLP, see the module docstring
+        self.rawln = False
+        self.rawln_allowed = os.environ.get('MBX_RAWLN', '1') == '1'      # A/B switch: 0 = the training sequencing without saves
+        self.Pk: Dict[str, torch.Tensor] = {}       # fc1 / fc2 of every MLP in the fragment order of mbx_mlp_fused_fwd
         # residual GEMM + the next LayerNorm forward in one launch (round 3, bf16 path; include/mbx.h): decided at the first forward
         # (the provider checks the device's workgroup -> XCD rule once).  Opt-in with MBX_RESID_LN=1: measured time-neutral at 64 clips
         self.resid_ln = None
@@ -241,6 +258,12 @@ class Engine:
             fn, ft, self.Bf, self.Rs = ops.fold_norm_weights(P, pairs, need_grad, self.T)
             self.Wn.update(fn)
             self.Wt.update(ft)
+            if self.rawln:
+                for stream in ('blocks_st', 'blocks_ts'):
+                    for i in range(cfg.depth):
+                        for m in ('mlp_s', 'mlp_t'):
+                            pre = f'{stream}.{i}.{m}'
+                            self.Pk[pre] = ops.mlp_pack_weights(self.Wn[pre + '.fc1'], self.Wn[pre + '.fc2'])
         else:
             self.Wn, self.Wt = (ops.prep_weights(P, linear_names(cfg), self.T, need_grad, x3=True) if self.x3 else
                                 ops.prep_weights(P, linear_names(cfg), self.T, need_grad))
@@ -261,6 +284,8 @@ class Engine:
         self.B, self.Tlen, self.M = B, T, M
         if self.resid_ln is None:
             self.resid_ln = (not self.x3) and bool(getattr(ops, 'can_fuse_resid_ln', lambda *_: False)(self.T, cfg.C, x.device))
+        self.rawln = (not need_grad and self.fold and self.drop_seed is None and self.rawln_allowed and
+                      bool(getattr(ops, 'can_fuse_mlp', lambda *_: False)(self.T, cfg)))
         self.prepare_weights(need_grad)
         h = self._f(M, C)
         if tta_perm is not None:
@@ -365,6 +390,10 @@ class Engine:
         M, C = self.M, cfg.C
         y = self._f(M, C)
         drop = dm is not None and (dm[0] > 0 or dm[3] > 0)
+        if self.rawln and nxt is not None:      # no-grad: the next sub-layer (an MLP) takes bf16(y) as its raw operand
+            y_t = self._t(M, C)
+            ops.gemm_nt_resid_t(a, self.Wn[lin], P[lin + '.bias'], x, y, y_t)
+            return y, RawRows(y_t, None, None)
         if nxt is not None and not drop and self.resid_ln:
             xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
             g, b = (None, None) if self.fold else (P[f'{pre}.{nxt}.weight'], P[f'{pre}.{nxt}.bias'])
@@ -378,18 +407,22 @@ class Engine:
     def _attn_fwd(self, x, pre, norm, attn, mode, need_grad, sub=0, ln=None, nxt=None):
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C = self.M, cfg.C
-        if ln is not None:            # LayerNorm(x) came with x from its producer
-            xn, mean, rstd = ln
-        else:
-            xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
-            if self.fold:
-                ops.layernorm_fwd(x, None, None, cfg.eps, xn, mean, rstd)
-            else:
-                ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
-        xn = self._mm(xn)
         qkv = self._t(M, 3 * C)
-        ops.gemm_nt(xn, self.Wn[f'{pre}.{attn}.qkv'], self.Bf[f'{pre}.{attn}.qkv'] if self.fold else self._bias(f'{pre}.{attn}.qkv'),
-                    EPI_STORE, out_t=qkv)
+        lin = f'{pre}.{attn}.qkv'
+        if isinstance(ln, RawRows) and ln.mean is not None:      # no-grad: the LayerNorm is applied in the qkv GEMM's epilogue
+            xn = mean = rstd = None
+            ops.gemm_nt_rawln(ln.t, self.Wn[lin], self.Bf[lin], self.Rs[lin], ln.mean, ln.rstd, qkv)
+        else:
+            if ln is not None and not isinstance(ln, RawRows):   # LayerNorm(x) came with x from its producer
+                xn, mean, rstd = ln
+            else:
+                xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+                if self.fold:
+                    ops.layernorm_fwd(x, None, None, cfg.eps, xn, mean, rstd)
+                else:
+                    ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
+            xn = self._mm(xn)
+            ops.gemm_nt(xn, self.Wn[lin], self.Bf[lin] if self.fold else self._bias(lin), EPI_STORE, out_t=qkv)
         dm = self._drops(pre, sub)
         o, lse = self._t(M, C), self._f(M, cfg.H)
         if dm is not None and dm[5] > 0:      # attn_drop: the counter-based mask is applied to the probabilities inside the kernel
@@ -406,6 +439,20 @@ class Engine:
     def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1, ln=None, nxt=None):
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C = self.M, cfg.C
+        if self.rawln:                # no-grad: the whole sub-layer is one kernel; the hidden never reaches HBM
+            lin = f'{pre}.{mlp}.fc1'
+            if isinstance(ln, RawRows):
+                a, raw = ln.t, True
+            else:
+                if ln is None:
+                    ln = (self._t(M, C), self._f(M), self._f(M))
+                    ops.layernorm_fwd(x, None, None, cfg.eps, *ln)
+                a, raw = ln[0], False
+            y = self._f(M, C)
+            y_t, mean, rstd = (self._t(M, C), self._f(M), self._f(M)) if nxt is not None else (None, None, None)
+            ops.mlp_fused_fwd(a, raw, self.Pk[f'{pre}.{mlp}'], self.Bf[lin], P[f'{pre}.{mlp}.fc2.bias'], self.Rs[lin] if raw else None,
+                              x, y, y_t, cfg.eps, mean, rstd)
+            return y, None, (RawRows(y_t, mean, rstd) if nxt is not None else None)
         if ln is not None:            # LayerNorm(x) came with x from the residual GEMM of the previous sub-layer
             xn, mean, rstd = ln
         else:
@@ -574,7 +621,7 @@ class Engine:
         if db is None:                     # qkv_bias=False: the column sums of dY are still needed for d(beta)
             db = self._f(dY.shape[1])
         ws = self._wstream()
-        dx_first = os.environ.get('MBX_FOLD_ORDER', '0') == '1'      # A/B: the dX GEMM (critical path) before the weight gradient
+        dx_first = self.fold_dx_first      # A/B: the dX GEMM (critical path) before the weight gradient
         if dx_first:
             dx = self._f(M, C)
             dx_t = self._t(M, C) if need_t else None

@@ -209,6 +209,42 @@ def test_baseline_shape_fixture_fwd_bwd(name, precision, recompute):
         assert not bad, f'bf16 per-tensor gradient error above max(3x the reference-under-autocast error, 8 % of the global norm): {bad}'
 
 
+@pytest.mark.parametrize('name', ['tiny_trained', 'lite_2x81', 'full_1x243'])
+def test_no_grad_path_on_fixtures(name, monkeypatch):
+    """The inference sequencing (raw-operand LayerNorm + fused MLP, engine.py `rawln`) against the reference-minted fixtures: the
+    same output gate as the training forward of the same precision, and agreement with the training sequencing run without saves
+    (MBX_RAWLN=0) at the bf16 noise floor.  fp32-class modes have no separate no-grad sequencing (checked: same bits)."""
+    z, cfg = load_golden(name)
+    if any(k.startswith('w.') for k in z.files):      # the tiny fixtures carry their weights
+        model = build_model(cfg)
+        model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('w.')}, strict=True)
+    else:                                             # the BASELINE-shape fixtures are rebuilt from the seed (checked against w_stats)
+        model = build_model(cfg, seed=0)
+        if int(z['trained_seed']) >= 0:
+            trained_like(model, int(z['trained_seed']))
+        got_w = np.asarray([[v.double().sum().item(), v.double().abs().sum().item()] for v in model.state_dict().values()])
+        assert np.allclose(got_w, z['w_stats'], rtol=1e-6, atol=1e-6)
+    model = model.to(DEV).eval()
+    x = torch.from_numpy(z['x']).to(DEV)
+    ac_out = float(z['autocast_out']) if 'autocast_out' in z.files else TOL_BF16_OUT
+    outs = {}
+    for raw in ('1', '0'):
+        monkeypatch.setenv('MBX_RAWLN', raw)
+        with torch.no_grad():
+            model.precision = 'bf16'
+            outs[raw] = model(x).float().cpu().numpy()
+            rep = model.get_representation(x).float().cpu().numpy()
+        e_out, e_rep = rel_l2(outs[raw], z['out']), rel_l2(rep, z['rep']) if 'rep' in z.files else 0.0
+        REPORT[f'nograd.{name}.bf16.rawln{raw}'] = dict(out=e_out, rep=e_rep)
+        assert e_out < min(2 * ac_out, max(TOL_BF16_OUT, ac_out)), (raw, e_out, ac_out)
+    assert rel_l2(outs['1'], outs['0']) < max(TOL_BF16_OUT, ac_out)
+    monkeypatch.setenv('MBX_RAWLN', '1')
+    with torch.no_grad():
+        model.precision = 'fp32'
+        o32 = model(x)
+    assert rel_l2(o32.cpu().numpy(), z['out']) < TOL_FP32
+
+
 @pytest.mark.timeout(900)
 def test_oracle_full_t243_fwd_bwd():
     """The numpy fp64 oracle itself (forward AND hand-written backward) on the full model at [1,243,17,3] with

@@ -110,6 +110,36 @@ def test_no_grad_saves_nothing_and_frozen_params_get_none():
     assert model.head.weight.grad is not None and model.joints_embed.weight.grad is None
 
 
+@pytest.mark.parametrize('name', ['tiny_default', 'tiny_trained'])
+def test_no_grad_raw_operand_sequencing(name):
+    """The no-grad path of a Block: residual GEMM + bf16(y), fused MLP (raw operand in, raw operand + statistics out), qkv GEMM
+    with the LayerNorm row constants in its epilogue -- against the reference output and against the training-path sequencing."""
+    z, cfg = load_golden(name)
+    model = build_model(cfg)
+    _load(model, z)
+    model.precision = 'fp32'
+    x = torch.from_numpy(z['x'])
+    ops, ops_plain = MockOps(), MockOps()
+    ops_plain.fuse_mlp = False
+    with torch.no_grad():
+        out = M.run(ops, model, x)
+        out_plain = M.run(ops_plain, model, x)
+        rep = M.run(MockOps(), model, x, return_rep=True)
+    assert rel_l2(out.numpy(), z['out']) < 5e-6 and rel_l2(out_plain.numpy(), z['out']) < 2e-6
+    assert rel_l2(rep.numpy(), z['rep']) < 5e-6
+    depth = cfg['depth']
+    # per level: 2 Blocks x (2 fused MLPs, 2 residual GEMMs that leave the raw operand, 1 qkv GEMM that consumes MLP statistics)
+    assert ops.calls.count('mlp_fused_fwd') == ops.calls.count('mlp_pack_weights') == 4 * depth
+    assert ops.calls.count('gemm_nt.resid_t') == 4 * depth and ops.calls.count('gemm_nt.rawln') == 2 * depth
+    assert ops.calls.count('gemm_nt.1') == ops.calls.count('gemm_nt.2') == 0          # no fc1 / fc2 / proj launches of the training path
+    assert ops.calls.count('layernorm_fwd') <= 2                                      # only the two Blocks of level 0 (their input has no producer kernel)
+    assert 'mlp_fused_fwd' not in ops_plain.calls and ops_plain.calls.count('gemm_nt.1') == 4 * depth
+    # with gradients enabled the training sequencing runs, whatever the provider offers
+    ops_g = MockOps()
+    M.run(ops_g, model, x.clone().requires_grad_(True)).sum().backward()
+    assert 'mlp_fused_fwd' not in ops_g.calls and 'gemm_nt.rawln' not in ops_g.calls
+
+
 def test_average_fusion_variant():
     z, cfg = load_golden('tiny_default')
     from oracle import dstformer_oracle as O
