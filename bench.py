@@ -285,6 +285,7 @@ def bench_block(dev, B=256, T=243, iters=5):
 
     def fwd_bwd():
         _, svs = fwd(True)
+        eng.gstream = eng.fold and eng.gstream_allowed      # (what Engine.backward decides)
         eng._block_bwd(dy, dy_t, svs, pre, 'st', None, last_needs_t=False)
 
     def timeit(fn):

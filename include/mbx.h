@@ -43,7 +43,8 @@ enum mbx_epilogue {
     MBX_EPI_LNBWD = 5, /* internal to mbx_gemm_nt_lnbwd (LayerNorm backward as a GEMM epilogue); not accepted by mbx_gemm_nt */
     MBX_EPI_RESID_LN = 6, /* internal to mbx_gemm_nt_resid_ln (residual GEMM + the next LayerNorm forward); not accepted by mbx_gemm_nt */
     MBX_EPI_RESID_T = 7,  /* internal to mbx_gemm_nt_resid_t (MBX_EPI_RESID + a bf16 copy of the output); not accepted by mbx_gemm_nt */
-    MBX_EPI_STORE_LN = 8  /* internal to mbx_gemm_nt_rawln (LayerNorm row constants applied in the epilogue); not accepted by mbx_gemm_nt */
+    MBX_EPI_STORE_LN = 8, /* internal to mbx_gemm_nt_rawln (LayerNorm row constants applied in the epilogue); not accepted by mbx_gemm_nt */
+    MBX_EPI_LNBWD_T = 9   /* internal to mbx_gemm_nt_lnbwd_t (MBX_EPI_LNBWD with the gradient residual stream in bf16) */
 };
 
 enum mbx_attn_mode {
@@ -131,6 +132,12 @@ int mbx_lnbwd_rowc(const float* part, int nb, const float* rstd, float* rowc, in
  * a bf16 [M,K] (dY), w bf16 [N,K] (the transposed folded weight), xhat bf16 [M,N].  N % 8 == 0, K % 64 == 0. */
 int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat, const float* rowc, const float* dres,
                       const float* extra, float* dx, void* dx_t, int M, int N, int K, void* stream);
+/* The same with the gradient of the residual stream carried as bf16 BETWEEN the four sub-layers of a Block (fp32 at the Block
+ * boundaries, fp32 accumulation and arithmetic in the kernel): dres_t bf16 [M,N]; dx f32 or NULL; dx_t bf16 or NULL (at least one
+ * of them).  Inside a Block dx_t alone is written -- it is the stream and the next dX / dW GEMMs' operand at once: 4 instead of 12
+ * bytes per element and launch.  Numerics: tools/gradstream_numerics.py (every gate of the bf16 path unchanged). */
+int mbx_gemm_nt_lnbwd_t(const void* a, const void* w, const void* xhat, const float* rowc, const void* dres_t,
+                        const float* extra, float* dx, void* dx_t, int M, int N, int K, void* stream);
 /* in place: dw[N,K] (= dY^T xhat, the folded weight gradient) <- gamma[k] dw[n,k] + db[n] beta[k];
  * dgamma[k] = sum_n w[n,k] dw'[n,k];  dbeta[k] = sum_n w[n,k] db[n].  ws: >= mbx_unfold_norm_grads_ws(N,K) bytes. */
 size_t mbx_unfold_norm_grads_ws(int N, int K);
@@ -218,6 +225,8 @@ int mbx_fuse_fwd(const float* x_st, const float* x_ts, const float* w, const flo
 int mbx_fuse_ln_fwd(const float* x_st, const float* x_ts, const float* w, const float* b, float* out, float* alpha,
                     const float* g1, const float* b1, void* xn1, const float* g2, const float* b2, void* xn2, float eps,
                     float* mean, float* rstd, int M, int C, int dtype, void* stream);
+/* backward: d_st / d_ts f32 [M,C] and their T-typed copies d_st_t / d_ts_t; d_st = d_ts = NULL writes the T-typed copies only
+ * (the gradient stream in the operand type, see mbx_gemm_nt_lnbwd_t) */
 size_t mbx_fuse_bwd_ws(int C);
 int mbx_fuse_bwd(const float* dh, const float* x_st, const float* x_ts, const float* alpha, const float* w,
                  float* d_st, float* d_ts, void* d_st_t, void* d_ts_t, float* dw, float* db, int M, int C,

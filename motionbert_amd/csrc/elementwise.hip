@@ -1086,8 +1086,10 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const float* __restrict__
                     g1s[k][i] = fmaf(dl1, a[k][i], g1s[k][i]);
                     g1t[k][i] = fmaf(dl1, t[k][i], g1t[k][i]);
                 }
-                store4<float>(d_st + (size_t)row * C + c, rs);
-                store4<float>(d_ts + (size_t)row * C + c, rt);
+                if (d_st != nullptr) {      // (NULL with the gradient stream in the operand type: the Blocks read d_st_t / d_ts_t only)
+                    store4<float>(d_st + (size_t)row * C + c, rs);
+                    store4<float>(d_ts + (size_t)row * C + c, rt);
+                }
                 store4<T>(d_st_t + (size_t)row * C + c, rs);
                 store4<T>(d_ts_t + (size_t)row * C + c, rt);
             }
@@ -1109,7 +1111,8 @@ extern "C" size_t mbx_fuse_bwd_ws(int C) { return (size_t)FUSE_BWD_BLOCKS * (4 *
 extern "C" int mbx_fuse_bwd(const float* dh, const float* x_st, const float* x_ts, const float* alpha, const float* w,
                             float* d_st, float* d_ts, void* d_st_t, void* d_ts_t, float* dw, float* db, int M, int C,
                             int dtype, void* ws, void* stream) {
-    MBX_CHECK_ARG(dh && x_st && x_ts && alpha && w && d_st && d_ts && d_st_t && d_ts_t && dw && db && ws, "fuse_bwd: null pointer");
+    MBX_CHECK_ARG(dh && x_st && x_ts && alpha && w && d_st_t && d_ts_t && dw && db && ws, "fuse_bwd: null pointer");
+    MBX_CHECK_ARG((d_st && d_ts) || (!d_st && !d_ts), "fuse_bwd: d_st and d_ts come together (both NULL: only the T-typed copies are written)");
     MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "fuse_bwd: bad shape");
     const int grid = clamp_grid((M + 3) / 4, FUSE_BWD_BLOCKS);
     const int n = 4 * C + 4;

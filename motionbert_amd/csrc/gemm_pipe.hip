@@ -119,6 +119,7 @@ __device__ __forceinline__ int sw_off(int row, int chunk) { return row * P_ROWB 
 // else trap: never a silently stale row); the host enables the path only after mbx_xcc_probe confirmed the blockIdx -> XCD rule.
 // The CU's own L1 cannot hold a stale copy: it is invalid at kernel start and this kernel never read y before (y != resid is checked).
 struct NtLnTail {
+    const bf16_t* dres_t;   // MBX_EPI_LNBWD_T: the incoming gradient of the residual stream as bf16 (instead of `resid` fp32)
     float* mean;
     float* rstd;
     const float* gamma;     // NULL: plain normalisation (folded affine part)
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
     if (dbg & 4) return;
     __builtin_amdgcn_s_barrier();                           // all waves are done reading the last stage
     char* er = smem + wave * (64 * EROW);                   // 9 KiB per wave, 72 KiB per workgroup
-    if constexpr (EPI == MBX_EPI_LNBWD) {
+    if constexpr (EPI == MBX_EPI_LNBWD || EPI == MBX_EPI_LNBWD_T) {
         // LayerNorm backward as the epilogue of the dX GEMM ("LayerNorm folding", elementwise.hip): acc = d(xhat),
         //   dx = dres [+ extra] + rstd acc - rstd c1 - xhat rstd c2,   rowc[m] = {rstd, rstd c1, rstd c2, -}.
         // Staging: 32 rows x 64 columns fp32 per pass (pitch 272 B, 8.5 KiB of the wave's 9 KiB), walked with eight lanes per row,
@@ -337,14 +338,24 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
 #endif
         constexpr int LNB_D = MBX_LNB_DEPTH;
         const int mb0 = m0 + wm * 64;
+        // LNBWD_T (round 4): the gradient of the residual stream travels BETWEEN the sub-layers of a Block as bf16 -- dres arrives as
+        // eight bf16 (one 16-byte load instead of two), and out_f may be NULL (the bf16 output is then the stream AND the next GEMM's
+        // operand); fp32 accumulation and arithmetic are unchanged.  tools/gradstream_numerics.py: every gate of the bf16 path holds.
+        constexpr bool DRES_T = EPI == MBX_EPI_LNBWD_T;
         float4 dy0[LNB_D], dy1[LNB_D], rc[LNB_D];
         uint4 xh[LNB_D];
 #define LNB_LOAD(P_)                                                                            \
         do {                                                                                    \
             const size_t mo_ = (size_t)min(mb0 + (P_) * 8 + rr8, M - 1);                        \
             rc[(P_) % LNB_D] = rowc[mo_];                                                       \
-            dy0[(P_) % LNB_D] = epi_load_f4<MBX_LD_LNB>(resid + mo_ * N + nc);                              \
-            dy1[(P_) % LNB_D] = epi_load_f4<MBX_LD_LNB>(resid + mo_ * N + nc + 4);                          \
+            if (DRES_T) {                                                                       \
+                const uint4 t_ = epi_load_u4<MBX_LD_LNB>(ln.dres_t + mo_ * N + nc);             \
+                dy0[(P_) % LNB_D] = make_float4(__uint_as_float(t_.x << 16), __uint_as_float(t_.x & 0xffff0000u), __uint_as_float(t_.y << 16), __uint_as_float(t_.y & 0xffff0000u)); \
+                dy1[(P_) % LNB_D] = make_float4(__uint_as_float(t_.z << 16), __uint_as_float(t_.z & 0xffff0000u), __uint_as_float(t_.w << 16), __uint_as_float(t_.w & 0xffff0000u)); \
+            } else {                                                                            \
+                dy0[(P_) % LNB_D] = epi_load_f4<MBX_LD_LNB>(resid + mo_ * N + nc);              \
+                dy1[(P_) % LNB_D] = epi_load_f4<MBX_LD_LNB>(resid + mo_ * N + nc + 4);          \
+            }                                                                                   \
             xh[(P_) % LNB_D] = epi_load_u4<MBX_LD_LNB>(aux + mo_ * N + nc);                                 \
         } while (0)
 #pragma unroll
@@ -382,8 +393,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
                         v[0] += e0.x; v[1] += e0.y; v[2] += e0.z; v[3] += e0.w;
                         v[4] += e1.x; v[5] += e1.y; v[6] += e1.z; v[7] += e1.w;
                     }
-                    epi_store16<MBX_ST_LNB>(out_f + o, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
-                    epi_store16<MBX_ST_LNB>(out_f + o + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
+                    if (!DRES_T || out_f) {
+                        epi_store16<MBX_ST_LNB>(out_f + o, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+                        epi_store16<MBX_ST_LNB>(out_f + o + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
+                    }
                     if (out_t)
                         epi_store16<MBX_ST_LNB>(out_t + o, make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])));
                 }
@@ -1182,6 +1195,28 @@ extern "C" int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat,
     return 0;
 }
 
+// mbx_gemm_nt_lnbwd with the gradient residual stream in bf16: dres_t bf16 [M,N]; dx f32 or NULL; dx_t bf16 or NULL (at least one)
+extern "C" int mbx_gemm_nt_lnbwd_t(const void* a, const void* w, const void* xhat, const float* rowc, const void* dres_t,
+                                   const float* extra, float* dx, void* dx_t, int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(a && w && xhat && rowc && dres_t && (dx || dx_t), "gemm_nt_lnbwd_t: null pointer");
+    MBX_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && K > 0 && K % 64 == 0, "gemm_nt_lnbwd_t: bad shape M=%d N=%d K=%d (N %% 8, K %% 64)", M, N, K);
+    MBX_CHECK_ARG((reinterpret_cast<uintptr_t>(rowc) & 15) == 0, "gemm_nt_lnbwd_t: rowc must be 16-byte aligned");
+    const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
+    const size_t shm = P_NSTAGE * P_STAGE;
+    if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_LNBWD_T>, shm, "gemm_nt_lnbwd_t")) return 1;
+    NtLnTail ln{};
+    ln.dres_t = (const bf16_t*)dres_t;
+    hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_LNBWD_T>), dim3((unsigned)ntn * ntm), dim3(512), shm, (hipStream_t)stream, (const bf16_t*)a,
+                       (const bf16_t*)w, (const float*)nullptr, (bf16_t*)dx_t, (bf16_t*)nullptr, dx, (const float*)nullptr, (const bf16_t*)xhat,
+                       M, N, K, ntn, reinterpret_cast<const float4*>(rowc), extra, ln
+#ifdef MBX_DIAG
+                       , 0, (long long*)nullptr
+#endif
+                       );
+    MBX_LAUNCH_CHECK("gemm_nt_lnbwd_t");
+    return 0;
+}
+
 // out_t = rstd (a . Wt - mean rsum) + b: the Linear behind a LayerNorm whose input row arrives RAW (a = bf16(y)) with its row
 // statistics -- the consumer side of include/mbx.h "LayerNorm as a raw operand" (qkv of the no-grad path)
 extern "C" int mbx_gemm_nt_rawln(const void* a, const void* w, const float* bias, const float* rsum, const float* mean, const float* rstd,
@@ -1230,7 +1265,7 @@ extern "C" int mbx_gemm_nt_resid_ln(const void* a, const void* w, const float* b
     static const int dbg = mbx_env_int("MBX_DBG", 0);
 #endif
     if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_RESID_LN>, shm, "gemm_nt_resid_ln")) return 1;
-    const NtLnTail ln{mean, rstd, gamma, beta, (unsigned*)ws, eps};
+    const NtLnTail ln{nullptr, mean, rstd, gamma, beta, (unsigned*)ws, eps};
     hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_RESID_LN>), dim3((unsigned)(8 * ntn * ((ntm + 7) / 8))), dim3(512), shm, s, (const bf16_t*)a,
                        (const bf16_t*)w, bias, (bf16_t*)xn, (bf16_t*)nullptr, y, resid, (const bf16_t*)nullptr, M, N, K, ntn,
                        (const float4*)nullptr, (const float*)nullptr, ln

@@ -163,6 +163,12 @@ class Engine:
         self.fold = (os.environ.get('MBX_FOLD_LN', '1') == '1' and not x3 and drop_seed is None and
                      bool(getattr(ops, 'can_fold', lambda *_: False)(tdtype, cfg)))
         self.fold_dx_first = os.environ.get('MBX_FOLD_ORDER', '0') == '1'
+        # Gradient residual stream in the operand type BETWEEN the four sub-layers of a Block (round 4; fp32 at the Block boundaries,
+        # fp32 arithmetic in the kernels): the folded LayerNorm-backward GEMM reads its dres as bf16 and writes ONLY the bf16 dx, which
+        # is the stream and the next GEMMs' operand at once -- 4 instead of 12 bytes per element and launch.  Numerics:
+        # tools/gradstream_numerics.py / profiles/r04_gradstream_numerics.txt (every gate unchanged).  MBX_GRAD_STREAM=0: the A/B switch.
+        self.gstream_allowed = os.environ.get('MBX_GRAD_STREAM', '1') == '1' and bool(getattr(ops, 'grad_stream_t', False))
+        self.gstream = False      # decided per backward (the folded sequencing only)
         self.Bf: Dict[str, torch.Tensor] = {}
         self.Rs: Dict[str, torch.Tensor] = {}
         # no-grad sequencing of a Block (decided per forward): raw-operand LayerNorm + fused MLP, see the module docstring
@@ -487,6 +493,7 @@ class Engine:
         M, C, R = self.M, cfg.C, cfg.R
         B, T, J = self.B, self.Tlen, cfg.J
         G = self.grads = grads
+        self.gstream = self.fold and self.gstream_allowed
         dpre = self._t(M, R)
         if saved.get('pool') is not None:
             _, persons, p_drop, seed = saved['pool']
@@ -513,7 +520,8 @@ class Engine:
             on_ready(0)
         for i in reversed(range(cfg.depth)):
             lv = saved['levels'][i]
-            d_st, d_ts = self._f(M, C), self._f(M, C)
+            # (gradient stream in the operand type: the Blocks read the T-typed copies only, the fp32 ones are not even written)
+            d_st, d_ts = (None, None) if (self.gstream and cfg.att_fuse) else (self._f(M, C), self._f(M, C))
             d_st_t, d_ts_t = self._t(M, C), self._t(M, C)
             if cfg.att_fuse:
                 ops.fuse_bwd(dh, lv['x_st'], lv['x_ts'], lv['alpha'], P[f'ts_attn.{i}.weight'],
@@ -590,7 +598,7 @@ class Engine:
             ops.attn_bwd_stats(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.Bf[lin], self.Rs[lin], part, self.B, self.Tlen, cfg.J, cfg.H,
                                cfg.scale, mode)
             del do
-            return self._fold_tail(dqkv, part, sv, lin, f'{pre}.{norm}', dy, extra, need_t)
+            return self._fold_tail(dqkv, part, sv, lin, f'{pre}.{norm}', dy, dy_t, extra, need_t)
         if dm is not None and dm[5] > 0:
             ops.attn_bwd(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode, drop=(dm[5], dm[6]))
         else:
@@ -609,10 +617,11 @@ class Engine:
                           dx, dx_t, G[f'{pre}.{norm}.weight'], G[f'{pre}.{norm}.bias'])
         return dx, dx_t
 
-    def _fold_tail(self, dY, part, sv, lin, norm, dy, extra, need_t):
+    def _fold_tail(self, dY, part, sv, lin, norm, dy, dy_t, extra, need_t):
         """Folded (LayerNorm -> Linear) pair, backward from the Linear's output gradient dY and its row dots `part`: weight
         gradient, then dx = dy [+ extra] + LayerNorm'(dY . W') as the epilogue of the dX GEMM, then the parameter gradients of
-        W, gamma and beta from the folded weight gradient."""
+        W, gamma and beta from the folded weight gradient.  With the gradient stream in the operand type (`gstream`) the incoming
+        dy is read as dy_t and, inside a Block (need_t), only the T-typed dx is written: returns (None, dx_t)."""
         cfg, ops, P, G = self.cfg, self.ops, self.P, self.grads
         M, C = self.M, cfg.C
         rowc = self._f(M, 4)
@@ -621,13 +630,18 @@ class Engine:
         if db is None:                     # qkv_bias=False: the column sums of dY are still needed for d(beta)
             db = self._f(dY.shape[1])
         ws = self._wstream()
-        dx_first = self.fold_dx_first      # A/B: the dX GEMM (critical path) before the weight gradient
-        if dx_first:
-            dx = self._f(M, C)
+        stream = self.gstream and dy_t is not None
+        dres = dy_t if stream else dy
+
+        def dx_gemm(extra):
+            dx = None if (stream and need_t) else self._f(M, C)
             dx_t = self._t(M, C) if need_t else None
-            if callable(extra):
+            if callable(extra):      # dual-stream backward: the other block's input gradient, awaited only now
                 extra = extra()
-            ops.gemm_nt_lnbwd(dY, self.Wt[lin], sv['xn'], rowc, dy, extra, dx, dx_t)
+            ops.gemm_nt_lnbwd(dY, self.Wt[lin], sv['xn'], rowc, dres, extra, dx, dx_t)
+            return dx, dx_t
+        if self.fold_dx_first:       # A/B: the dX GEMM (critical path) before the weight gradient
+            out = dx_gemm(extra)
         if ws is None:
             ops.gemm_tn(dY, sv['xn'], G[lin + '.weight'], db)
             ops.unfold_norm_grads(G[lin + '.weight'], db, P[lin + '.weight'], P[norm + '.weight'], P[norm + '.bias'],
@@ -640,14 +654,7 @@ class Engine:
                                       G[norm + '.weight'], G[norm + '.bias'])
             for t in (dY, sv['xn'], db):
                 t.record_stream(ws)
-        if dx_first:
-            return dx, dx_t
-        dx = self._f(M, C)
-        dx_t = self._t(M, C) if need_t else None
-        if callable(extra):      # dual-stream backward: the other block's input gradient, awaited only now
-            extra = extra()
-        ops.gemm_nt_lnbwd(dY, self.Wt[lin], sv['xn'], rowc, dy, extra, dx, dx_t)
-        return dx, dx_t
+        return out if self.fold_dx_first else dx_gemm(extra)
 
     def _mlp_bwd(self, dy, dy_t, sv, pre, norm, mlp, extra, need_t):
         cfg, ops, P, G = self.cfg, self.ops, self.P, self.grads
@@ -674,7 +681,7 @@ class Engine:
             lin = f'{pre}.{mlp}.fc1'
             part = self._f(cfg.hidden // 64, M, 2)
             ops.gemm_nt_dgelu_stats(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], du, sv['u'], self.Bf[lin], self.Rs[lin], part)
-            return self._fold_tail(du, part, sv, lin, f'{pre}.{norm}', dy, extra, need_t)
+            return self._fold_tail(du, part, sv, lin, f'{pre}.{norm}', dy, dy_t, extra, need_t)
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], None, EPI_DGELU, out_t=du, aux_t=sv['u'])
         if dm is not None and dm[0] > 0:                      # backward of the drop after the activation (commutes with GELU')
             ops.dropout(du, du, dm[0], dm[2])

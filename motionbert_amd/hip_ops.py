@@ -40,6 +40,7 @@ SIGNATURES = {
     'mbx_gemm_nt_dgelu_stats': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
     'mbx_lnbwd_rowc': (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     'mbx_gemm_nt_lnbwd': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
+    'mbx_gemm_nt_lnbwd_t': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
     'mbx_gemm_nt_resid_ln_ws': (_sz, [_i]),
     'mbx_gemm_nt_resid_ln': (_i, [_vp] * 7 + [_f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'mbx_xcc_probe': (_i, [_vp, _i, _vp]),
@@ -106,6 +107,7 @@ class HipOps:
     """Kernel provider backed by libmbx.so.  Stateless apart from size caches."""
 
     multi_stream = True   # every call takes the current stream: safe to drive from several HIP streams
+    grad_stream_t = True  # mbx_gemm_nt_lnbwd_t exists: the gradient residual stream may travel as bf16 inside a Block
 
     def __init__(self, lib: Optional[C.CDLL] = None):
         self.lib = lib or load_library()
@@ -253,9 +255,11 @@ class HipOps:
         self._ck(self.lib.mbx_lnbwd_rowc(_p(part), nb, _p(rstd), _p(rowc), M, int(C), self._stream()))
 
     def gemm_nt_lnbwd(self, a_t, w_t, xhat, rowc, dres, extra, dx, dx_t):
+        """dres fp32: dx fp32 (+ optional bf16 copy dx_t).  dres bf16 (the gradient stream inside a Block): dx and dx_t both optional."""
         M, K = a_t.shape
         N = w_t.shape[0]
-        self._ck(self.lib.mbx_gemm_nt_lnbwd(_p(a_t), _p(w_t), _p(xhat), _p(rowc), _p(dres), _p(extra), _p(dx), _p(dx_t), M, N, K, self._stream()))
+        fn = self.lib.mbx_gemm_nt_lnbwd_t if dres.dtype == torch.bfloat16 else self.lib.mbx_gemm_nt_lnbwd
+        self._ck(fn(_p(a_t), _p(w_t), _p(xhat), _p(rowc), _p(dres), _p(extra), _p(dx), _p(dx_t), M, N, K, self._stream()))
 
     # ------------------------------------------------------------------ raw-operand LayerNorm + fused MLP (bf16 no-grad path)
     @staticmethod

@@ -106,12 +106,13 @@ class MockOps:
 
     def gemm_nt_lnbwd(self, a_t, w_t, xhat, rowc, dres, extra, dx, dx_t):
         """dx = dres [+ extra] + rowc.x (a . w^T) - rowc.y - xhat rowc.z;  dx_t = T copy."""
-        self._log('gemm_nt.lnbwd')
+        self._log('gemm_nt.lnbwd' + ('' if dx is not None else '.stream'))
         acc = a_t.float() @ w_t.float().t()
-        r = dres + rowc[:, 0:1] * acc - rowc[:, 1:2] - xhat.float() * rowc[:, 2:3]
+        r = dres.float() + rowc[:, 0:1] * acc - rowc[:, 1:2] - xhat.float() * rowc[:, 2:3]      # dres: fp32, or T inside a Block (gradient stream)
         if extra is not None:
             r = r + extra
-        dx.copy_(r)
+        if dx is not None:
+            dx.copy_(r)
         if dx_t is not None:
             dx_t.copy_(r.to(dx_t.dtype))
 
@@ -195,6 +196,7 @@ class MockOps:
             raise ValueError(epi)
 
     fuse_resid_ln = True      # tests switch it off to exercise the unfused sequencing
+    grad_stream_t = True      # gemm_nt_lnbwd takes a T-typed dres and may skip the fp32 dx (the gradient stream inside a Block)
 
     def can_fuse_resid_ln(self, tdtype, N, device=None):
         return bool(self.fuse_resid_ln)
@@ -416,10 +418,12 @@ class MockOps:
         dw.copy_(dl.t() @ torch.cat([x_st, x_ts], -1))
         db.copy_(dl.sum(0))
         dcat = dl @ w
-        d_st.copy_(dh * alpha[:, 0:1] + dcat[:, :C])
-        d_ts.copy_(dh * alpha[:, 1:2] + dcat[:, C:])
-        d_st_t.copy_(d_st.to(d_st_t.dtype))
-        d_ts_t.copy_(d_ts.to(d_ts_t.dtype))
+        r_st, r_ts = dh * alpha[:, 0:1] + dcat[:, :C], dh * alpha[:, 1:2] + dcat[:, C:]
+        if d_st is not None:          # (None with the gradient stream in the operand type: only the T-typed copies are written)
+            d_st.copy_(r_st)
+            d_ts.copy_(r_ts)
+        d_st_t.copy_(r_st.to(d_st_t.dtype))
+        d_ts_t.copy_(r_ts.to(d_ts_t.dtype))
 
     def average(self, x_st, x_ts, out):
         self._log('average')

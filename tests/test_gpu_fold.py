@@ -156,6 +156,27 @@ def test_gemm_nt_lnbwd(ops, M, N, K, with_extra, with_t):
         assert bool((g[1][M] == 7.0).all()), 'gemm_nt_lnbwd wrote past dx_t'
 
 
+@pytest.mark.parametrize('with_extra,with_f,with_t', [(False, False, True), (True, True, False), (True, True, True), (False, True, False)])
+@pytest.mark.parametrize('M,N,K', [(4131, 512, 1536), (4131, 512, 1024), (1000, 64, 192), (264384 // 16, 512, 1536)])
+def test_gemm_nt_lnbwd_bf16_gradient_stream(ops, M, N, K, with_extra, with_f, with_t):
+    """mbx_gemm_nt_lnbwd_t (round 4): the same epilogue with dres arriving as bf16 and either output optional -- inside a Block only
+    the bf16 dx is written (it is the gradient stream and the next GEMMs' operand at once)."""
+    a, w = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, dtype=BF, scale=0.05)
+    xhat, rowc = rnd(M, N, seed=3, dtype=BF), rnd(M, 4, seed=4)
+    dres, extra = rnd(M, N, seed=5, dtype=BF), (rnd(M, N, seed=6) if with_extra else None)
+    mk = lambda: [torch.full((M + 1, N), 7.0, device=DEV) if with_f else None, torch.full((M + 1, N), 7.0, device=DEV, dtype=BF) if with_t else None]
+    g, r = mk(), mk()
+    ops.gemm_nt_lnbwd(a, w, xhat, rowc, dres, extra, g[0][:M] if with_f else None, g[1][:M] if with_t else None)
+    MockOps().gemm_nt_lnbwd(a, w, xhat, rowc, dres, extra, r[0][:M] if with_f else None, r[1][:M] if with_t else None)
+    tag = f'M{M}.N{N}.K{K}.{"x" if with_extra else "-"}{"f" if with_f else "-"}{"t" if with_t else "-"}'
+    if with_f:
+        check(f'gemm_nt_lnbwd_t.dx.{tag}', g[0][:M], r[0][:M], 2e-5)
+        assert bool((g[0][M] == 7.0).all()), 'gemm_nt_lnbwd_t wrote past dx'
+    if with_t:
+        check(f'gemm_nt_lnbwd_t.dx_t.{tag}', g[1][:M], r[1][:M], 4e-3)
+        assert bool((g[1][M] == 7.0).all()), 'gemm_nt_lnbwd_t wrote past dx_t'
+
+
 @pytest.mark.parametrize('N,K', [(1536, 512), (1024, 512), (192, 64), (200, 72)])
 def test_unfold_norm_grads(ops, N, K):
     dw, db, w = rnd(N, K, seed=1), rnd(N, seed=2), rnd(N, K, seed=3, scale=0.05)

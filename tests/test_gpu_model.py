@@ -26,6 +26,21 @@ TOL_FP32 = 1e-3          # the north-star gate
 TOL_BF16_OUT = 4e-2      # bf16 noise floor of the reference under autocast
 TOL_BF16_GRAD = 6e-2     # global relative L2 over all parameter gradients in bf16 mode
 
+# ---- Gate ledger: every tolerance of this file, and the commit that last changed it.  FROZEN since round 3:
+# a kernel change that needs a looser number here is a kernel bug until proven otherwise; round 4 changed none of them.
+#   gate                                                                     value                                   last changed
+#   fp32 / bf16x3: output, dx, global and per-tensor gradient (fixtures)     TOL_FP32 = 1e-3                         5c6b953 (round 1)
+#   bf16: output                                                             < min(2 x autocast, max(4e-2, autocast)) aaabbfb (round 2)
+#   bf16: global gradient                                                    < min(2 x autocast, max(0.08, autocast)) aaabbfb (round 2)
+#   bf16: per-tensor gradient                                                <= max(3 x autocast, 0.08 of the global norm)   def31fb (round 3: 0.05 -> 0.08
+#                                                                              with LayerNorm folding, profiles/r03_fold_numerics.txt)
+#   bf16x3 per tensor, chaotic oracle case / recompute fixtures              3e-3                                    347c9a1 / 7ad8d74 (round 2 / 3)
+#   bf16 on the chaotic oracle case                                          out < 0.0778, global gradient < 1.509   fc24144 (round 2: the
+#                                                                              reference's own autocast error on that configuration)
+#   TOL_BF16_GRAD (tiny fixtures, shape sweep)                               6e-2                                    7b55b57 (round 1)
+#   fold vs plain per tensor (tests/test_gpu_fold.py)                        <= max(2 x plain + 0.01, 0.08)          6559556 (round 3)
+#   no-grad path (round 4, new test, test_no_grad_path_on_fixtures)          the bf16 output gate above, unchanged
+
 
 def grad_errors(got, ref):
     """(global rel-L2 over all tensors, worst per-tensor error, its name).  A tensor's error is
@@ -564,10 +579,18 @@ def test_full_size_properties(recompute):
     out2, g2 = fwd_bwd(x, cot)
     assert torch.equal(out1, out2) and torch.equal(g1, g2), 'the path must be deterministic (no atomics anywhere)'
     assert torch.isfinite(out1).all() and torch.isfinite(g1).all()
-    # clips are independent: a sub-batch gives the same rows (same kernels, same per-token arithmetic)
+    # clips are independent: a sub-batch gives the same rows (same kernels, same per-token arithmetic) -- within the no-grad
+    # sequencing (round 4: raw-operand LayerNorm + fused MLP, a different kernel set from the training forward) ...
     with torch.no_grad():
         sub = model(x[5:9])
-    assert torch.equal(sub, out1[5:9])
+        full_ng = model(x)
+    assert torch.equal(sub, full_ng[5:9])
+    # ... and within the training sequencing
+    sub_g = model(x[5:9].clone().requires_grad_(True)).detach()
+    assert torch.equal(sub_g, out1[5:9])
+    # the two sequencings are two bf16 realisations of the same function
+    assert float((full_ng - out1).norm() / out1.norm()) < TOL_BF16_OUT
+    REPORT['full_size.nograd_vs_train_forward' + ('.recompute' if recompute else '')] = float((full_ng - out1).norm() / out1.norm())
     # backward is linear in the cotangent (power-of-two scale: exact in floating point up to the bf16 roundings of
     # intermediate gradients, which scale exactly too)
     _, g4 = fwd_bwd(x, cot, scale=4.0)

@@ -50,7 +50,10 @@ def test_engine_fp32_matches_reference_gradients(name, fold, resid_ln):
     assert ops.calls.count('attn_bwd.0' + sfx) == ops.calls.count('attn_bwd.1' + sfx) == 2 * depth
     # folded: the only stand-alone LayerNorm backward left is the final `norm`; every Block LayerNorm runs as a GEMM epilogue
     assert ops.calls.count('layernorm_bwd') == (1 if fold else 8 * depth + 1)
-    assert ops.calls.count('gemm_nt.lnbwd') == ops.calls.count('unfold_norm_grads') == ops.calls.count('lnbwd_rowc') == (8 * depth if fold else 0)
+    n_lnbwd = ops.calls.count('gemm_nt.lnbwd') + ops.calls.count('gemm_nt.lnbwd.stream')
+    assert n_lnbwd == ops.calls.count('unfold_norm_grads') == ops.calls.count('lnbwd_rowc') == (8 * depth if fold else 0)
+    # gradient stream in the operand type: the three inner LayerNorm-backward GEMMs of every Block write no fp32 dx
+    assert ops.calls.count('gemm_nt.lnbwd.stream') == (6 * depth if fold else 0)
     # forward: 8 residual GEMMs per level; 6 of them (all but each Block's last) carry the next LayerNorm
     assert ops.calls.count('gemm_nt.resid_ln') == (6 * depth if resid_ln else 0)
     assert ops.calls.count('gemm_nt.resid_ln') + ops.calls.count('gemm_nt.2') == 8 * depth
