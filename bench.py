@@ -173,8 +173,9 @@ def cpu_baseline(cfg, T, budget_s=20.0):
     """The CPU number beside the GPU number.  North star / SURVEY 8d: the UNMODIFIED reference `lib/model/DSTformer.py`
     (fp32, same loss, fwd+bwd) on the host cores -- used whenever a reference checkout is reachable
     ($MOTIONBERT_REFERENCE or /root/reference; it is imported read-only, never copied, bytecode writing off) ->
-    kind "reference".  The GPU box has no reference checkout: there the torch fp32 port of the same path
-    (oracle/torch_ops.py driven by the product's sequencing) is timed instead -> kind "port"; `sample` says which and why."""
+    kind "reference".  The GPU box has no reference checkout: there a plain torch restatement of the reference model
+    (oracle/torch_model.py: the same ATen operator mix and autograd backward) is timed instead -> kind "port", with the measured
+    port / reference ratio of the build container beside it (`port_over_reference`); `sample` says which and why."""
     cores = usable_cores()
     torch.set_num_threads(cores)
     ref_dir = os.environ.get('MOTIONBERT_REFERENCE', '/root/reference')
@@ -201,23 +202,40 @@ def cpu_baseline(cfg, T, budget_s=20.0):
                                f'{what}, {cores} threads, CPU: {_cpu_name()}')
         except Exception as e:     # fall through to the port, and say why
             why_port = f'importing the reference from {ref_dir} failed: {type(e).__name__}: {e}'
-    from motionbert_amd import DSTformer, model as M
-    from oracle.torch_ops import MockOps
+    # The port: oracle/torch_model.py -- the reference's operator mix (addmm / bmm / softmax / layer-norm / gelu, autograd backward) as
+    # one plain torch function over the same parameters.  Same batch, same loss, same thread count as the reference leg above.
+    from motionbert_amd import DSTformer
+    from oracle import torch_model as TM
     torch.manual_seed(0)
     m = DSTformer(norm_layer=partial(nn.LayerNorm, eps=1e-6), **cfg)
-    m.precision = 'fp32'
+    P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    Bc = 2
 
     def run(Tc, iters):
-        x, gt = make_batch(1, Tc, cfg['num_joints'], 1, 'cpu')
+        x, gt = make_batch(Bc, Tc, cfg['num_joints'], 1, 'cpu')
         t0 = time.time()
         for _ in range(iters):
-            m.zero_grad(set_to_none=True)
-            pose_loss(M.run(MockOps(), m, x), gt).backward()
+            for p in P.values():
+                p.grad = None
+            pose_loss(TM.forward(P, x, cfg['depth'], cfg['num_heads'], eps=1e-6), gt).backward()
         return (time.time() - t0) / iters
-    value, what = _bounded_rate(run, cfg, T, 1, budget_s)
-    return dict(value=round(value, 4), unit='clips/s', cores=cores, kind='port',
-                sample=f'torch fp32 port (oracle/torch_ops.py) of the full model fwd+bwd ({why_port}), {what}, {cores} threads, CPU: {_cpu_name()}; '
-                       'port vs unmodified reference on the same cores: tools/cpu_calibration.py, log in profiles/r03_cpu_calibration.txt')
+    value, what = _bounded_rate(run, cfg, T, Bc, budget_s)
+    cal = _port_calibration()
+    return dict(value=round(value, 4), unit='clips/s', cores=cores, kind='port', port_over_reference=cal,
+                sample=f'plain torch fp32 restatement of the reference model (oracle/torch_model.py: same ATen operators, autograd backward) fwd+bwd '
+                       f'({why_port}), {what}, {cores} threads = every core this container may use (affinity mask / cgroup quota; the host has '
+                       f'{os.cpu_count()} hardware threads), CPU: {_cpu_name()}; port / unmodified reference on the same cores, legs alternated: '
+                       f'{cal["mean"] if cal else "n/a"} +- {cal["spread"] if cal else "n/a"} (tools/cpu_calibration.py in the build container, profiles/r04_cpu_calibration.txt)')
+
+
+def _port_calibration():
+    """{'mean', 'spread', 'n'} of port / reference from the committed calibration log (build container: the GPU box has no reference)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r04_cpu_calibration.txt')) as f:
+            d = json.load(f)
+        return dict(mean=d['port_over_reference_mean'], spread=d['port_over_reference_spread'], n=len(d['runs']), where='build container')
+    except Exception:
+        return None
 
 
 PMC_TABLE = next((p for p in (os.path.join(ROOT, 'profiles', f'r0{r}_pmc_bench.txt') for r in (3, 2)) if os.path.exists(p)),
@@ -459,9 +477,9 @@ def main():
                    f'[{B},243,17,3] (mask + noise, mpjpe + 0.5 n_mpjpe + 20 velocity); augmentation, losses and AdamW as device kernels; value counts '
                    f'243-frame-equivalent clips ({frames} frames / 243 per macro step per GPU)')
 
-    def pose_step():
+    def pose_step(n=net):
         opt.zero_grad(set_to_none=True)
-        total, losses = fused_pose_loss(net(x), gt, LAMBDA_SCALE, LAMBDA_VELOCITY)
+        total, losses = fused_pose_loss(n(x), gt, LAMBDA_SCALE, LAMBDA_VELOCITY)
         total.backward()
         opt.step()
         return losses
@@ -479,6 +497,8 @@ def main():
         if i == 0:
             torch.cuda.synchronize()
             log(f'first step done, HBM in use {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
+    if world > 1 and hasattr(net, 'diagnostics'):
+        net.diagnostics = {}
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -492,6 +512,41 @@ def main():
     ms = dt / args.steps * 1e3
     clips = wl_units * world * args.steps / dt
     log(f'timed region: {ms:.2f} ms/step, {clips:.1f} clips/s')
+
+    # ---- N > 1: make the run self-diagnosing -- how many ranks really took part, what the gradient exchange
+    # moved and how much of it was NOT hidden under backward, and the same step WITHOUT the exchange on this very GPU in this very
+    # process (the N = 1 leg the scaling efficiency is quoted against; weak scaling: the per-GPU work is the same)
+    multi = None
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        diag = getattr(net, 'diagnostics', None) or {}
+        if hasattr(net, 'diagnostics'):
+            net.diagnostics = None
+        waits = [e0.elapsed_time(e1) for e0, e1 in diag.get('wait_events', [])]
+        nb = len(diag.get('bucket_bytes', [])) // max(1, len(waits)) if waits else 0
+        single_ms = None
+        if args.workload == 'pose':
+            for _ in range(2):
+                pose_step(model)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(min(args.steps, 5)):
+                pose_step(model)
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t1) / min(args.steps, 5) * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            single_ms = float(t.item())
+        multi = dict(world_size_seen=int(round(float(ones.item()))), backend=str(dist.get_backend()),
+                     allreduce_exposed_ms=round(sum(waits) / len(waits), 3) if waits else None,
+                     bucket_bytes=diag.get('bucket_bytes', [])[:nb], buckets_per_step=nb,
+                     gradient_bytes_per_step=int(sum(diag.get('bucket_bytes', [])[:nb])),
+                     single_gpu_ms_per_step_same_process=round(single_ms, 3) if single_ms else None,
+                     scaling_efficiency=round(single_ms / ms, 4) if single_ms else None,
+                     note='exposed = time the compute stream waits for the outstanding bucket all-reduces at the end of backward (HIP events '
+                          'around the wait, rank 0, mean over the timed steps); single-GPU leg = the same step on the bare replica, no '
+                          'gradient exchange, max over ranks; efficiency = single-GPU ms / N-GPU ms (weak scaling)')
+        log(f'multi-GPU diagnostics: {multi}')
 
     # ---- BASELINE config 1 beside the headline: the same model and batch forward-only (eval, no_grad), rank 0 at N=1
     fwd_only = None
@@ -703,7 +758,7 @@ def main():
                    'global_batch': B * world, 'frames': T, 'parallelism': f'dp{world}'},
         'model_tflops': round(flops_step * world / (ms * 1e-3) / 1e12, 1),
         'model_mfma_frac': round(flops_step / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS), 4),
-        'roofline': roof, 'kernel_breakdown_ms': breakdown, 'forward_only': fwd_only, 'gate_1e-3_modes': gate_modes, 'block_b256': block, 'config3_b32': cfg3, 'full_model_b256': full256, 'config4_pretrain': cfg4, 'config5_action': cfg5,
+        'multi_gpu': multi, 'roofline': roof, 'kernel_breakdown_ms': breakdown, 'forward_only': fwd_only, 'gate_1e-3_modes': gate_modes, 'block_b256': block, 'config3_b32': cfg3, 'full_model_b256': full256, 'config4_pretrain': cfg4, 'config5_action': cfg5,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -41,9 +41,7 @@
 template <bool SHARED> struct AttnBlock { static constexpr int THREADS = SHARED ? 512 : 256, WAVES = THREADS / 64; };
 // the dK/dV kernel needs ~170 VGPRs (two 32x64 accumulators per lane besides the score fragments): eight waves per
 // workgroup would not raise its occupancy, and four waves with eight key blocks each measured faster
-#ifndef MBX_ATTN_KV_THREADS
-#define MBX_ATTN_KV_THREADS 256
-#endif
+constexpr int MBX_ATTN_KV_THREADS = 256;
 template <bool SHARED> struct AttnBlockKV { static constexpr int THREADS = SHARED ? MBX_ATTN_KV_THREADS : 256, WAVES = THREADS / 64; };
 
 // ------------------------------------------------------------------------------------------------
@@ -265,9 +263,7 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (sizeof(T) == 2 && !DRO
     const int qb = SHARED ? wave : 0;
     const int q = qb * 32 + (lane & 31);
     // this lane's query row is requested BEFORE the K / V fill (round 3): one memory round trip for the prologue instead of two
-#ifndef MBX_ATTN_Q_EARLY
-#define MBX_ATTN_Q_EARLY 1
-#endif
+constexpr int MBX_ATTN_Q_EARLY = 1;
     BReg<T, HD> qreg;
     if (MBX_ATTN_Q_EARLY && qb < nfr)
         qreg.load(qkv + (P.tok0 + (size_t)min(q, P.L - 1) * P.tstep) * C3 + (size_t)P.h * HD, g, pvalid && q < P.L);
@@ -597,9 +593,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     const T* dobase = d_o + P.tok0 * C + (size_t)P.h * HD;
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
-#ifndef MBX_ATTN_SMALL_EARLY
-#define MBX_ATTN_SMALL_EARLY 1
-#endif
+constexpr int MBX_ATTN_SMALL_EARLY = 1;
     constexpr bool EARLY = MBX_ATTN_SMALL_EARLY && sizeof(T) == 2;
     uint4 vec_reg = make_uint4(0u, 0u, 0u, 0u);      // this lane's entry of the row-dot vectors (3 hd / 4 <= 48 entries), parked in registers
     if constexpr (EARLY) {
@@ -827,9 +821,7 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
 
     // ---- the loads of the per-query statistics (dO . O, lse: four lanes per row, KP <= 256 rows = one pass of the 1024 threads) go
     // out FIRST, so that their latency runs under the tile fill instead of after it (MBX_ATTN_STAT_EARLY=0: the old order) ----
-#ifndef MBX_ATTN_STAT_EARLY
-#define MBX_ATTN_STAT_EARLY 1
-#endif
+constexpr int MBX_ATTN_STAT_EARLY = 1;
     const int sr = tid >> 2, spart = tid & 3;
     uint2 sx[HD / 16], sy[HD / 16];
     float sl = 0.f;

@@ -23,9 +23,6 @@ __device__ __forceinline__ float gelu_fast(float u) {
 // needs no exponential, and every other operation is a packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32):
 //     gelu(u) = u Phi(u) = (u + |u| erf(|u| / sqrt 2)) / 2 = ((u + a) - a r^16) / 2,   a = |u|,  r = 1 / D(a),
 // with 2^(-k/2) folded into the coefficients of D.  ~54 issue cycles per element; fp32 evaluation error 7e-7 absolute.
-#ifndef MBX_GELU_PK
-#define MBX_GELU_PK 1
-#endif
 __device__ __forceinline__ mbx_f32x2_t gelu_fast2(mbx_f32x2_t u) {
     const mbx_f32x2_t a = {fabsf(u[0]), fabsf(u[1])};
     mbx_f32x2_t d = a * 5.382975e-06f + 4.8890636e-05f;      // a6 / 8, a5 / 2^2.5

@@ -1,24 +1,33 @@
-// Pipelined bf16 MFMA GEMMs for gfx950 (the throughput path; gemm.hip keeps the fp32 parity kernels).
+// Pipelined bf16 MFMA GEMMs for gfx950 (the throughput path; gemm.hip keeps the fp32 parity kernels, mlp_fused.hip the fused MLP).
 //
-// Structure (both kernels): 512-thread workgroup = 8 waves (2 per SIMD), one workgroup per CU,
-// a 3-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without touching
-// VGPRs), two k-tiles in flight behind the one being multiplied, ONE raw s_barrier per k-tile and
-// counted s_waitcnt vmcnt(N) (never 0 inside the loop) so that the DMA of tiles t+1, t+2 stays in
-// flight across the barrier while the MFMAs of tile t run.
-//
-//   gemm_nt_pipe : acc[M,N] = A[M,K] . W[N,K]^T, 256 x 128 output tile, wave grid 4(M) x 2(N), each wave
-//                  64 x 64 = 2 x 2 MFMA 32x32x16 tiles; stage = A [256][64] + W [128][64] bf16 = 48 KiB.
-//                  LDS image: rows of 128 B, 16-byte chunk c of row r at physical chunk c ^ ((r >> 1) & 7)
-//                  (conflict-free ds_read_b128 fragment reads).  LDS-DMA writes lane-linear, so the
-//                  swizzle is applied to the per-lane SOURCE address (same involution on both sides).
-//   gemm_tn_pipe : dW[N,K] = dY[M,N]^T . A[M,K] (contraction over the TOKEN dimension, which is the
-//                  slow dimension of both operands).  The tiles are staged untransposed,
-//                  [64 tokens][256 n] and [64 tokens][128 k], and the MFMA fragments are fetched with the
-//                  gfx950 transpose read ds_read_b64_tr_b16: lane r of a 16-lane group supplies the
-//                  address of 4 consecutive elements of token row (r >> 2), column block 4 (r & 3); the
-//                  hardware returns to lane i the 4 consecutive TOKENS of column i (mapping measured on
-//                  hardware with tools/probes/tr_probe.hip).  256 x 128 output tile, split over the
-//                  token dimension, fp32 partial tiles folded by colsum (deterministic, no atomics).
+// What ships, and which launches of a training step (64 clips) run on it:
+//   gemm_nt_pp256_kernel<EPI, X3>   acc[M,N] = A[M,K] . W[N,K]^T, 256 x 256 tile, 8 waves as 2 (M) x 4 (N) of 128 x 64 (4 x 2 MFMA
+//                                   32x32x16 tiles), BK = 32, 4-stage 32 KiB LDS ring filled by LDS-DMA, ONE workgroup per CU,
+//                                   PING-PONG schedule (waves 4-7 one phase behind waves 0-3: while one wave of a SIMD reads its
+//                                   fragments the other issues its 16 MFMAs).  Epilogues: STORE (qkv, every plain dX GEMM),
+//                                   GELU (fc1), TANH (pre_logits), DGELU (+ the row dots of the folded LayerNorm backward),
+//                                   STORE_LN (round 4, no-grad path: LayerNorm row constants applied to the accumulator).
+//                                   X3 = the split-operand fp32-class mode (three bf16 passes over hi / lo planes).
+//   gemm_nt_pipe_kernel<EPI>        the same product on a 256 x 128 tile, 8 waves as 4 x 2 of 64 x 64, 3-stage 24 KiB ring, TWO
+//                                   workgroups per CU; carries the epilogues that stream fp32: RESID (proj, fc2: + residual),
+//                                   RESID_T (round 4: + a bf16 copy of the output), LNBWD / LNBWD_T (LayerNorm backward as the
+//                                   epilogue of the dX GEMM; _T: the gradient residual stream arrives and leaves as bf16),
+//                                   RESID_LN (opt-in: the row block's last column tile also normalises it).
+//   gemm_tn_pipe256_kernel<X3>      dW[N,K] = dY[M,N]^T . A[M,K] (contraction over the TOKEN dimension, the slow dimension of both
+//                                   operands): tiles staged untransposed, fragments fetched with the gfx950 transpose read
+//                                   ds_read_b64_tr_b16 (inline asm: see tr_frag_a), 256 x 256 output tile, token dimension split
+//                                   over workgroups, fp32 partial tiles folded by a deterministic column sum; the same ping-pong
+//                                   schedule; bias gradient as packed-bf16 dots spread evenly over every wave of every workgroup.
+//   gemm_tn_pipe_kernel             the 256 x 128 weight-gradient kernel for N or K < 256 (MotionBERT-Lite's C = 256 shapes use
+//                                   the 256 x 256 one as well; this serves the small tails).
+// LDS image of every NT stage: rows of 64 B = four 16-byte chunks, chunk c of row r at physical chunk c ^ ((r >> 2) & 3)
+// (conflict-free ds_read_b128 fragment reads).  LDS-DMA (global_load_lds_dwordx4) writes lane-linear, so the swizzle is applied to
+// the per-lane SOURCE address -- the same involution on both sides.  One raw s_barrier per phase and counted s_waitcnt vmcnt(N)
+// (never 0 inside a loop) keep two or three k-tiles in flight across the barriers.  Tile -> workgroup orders are XCD-aware
+// (xcd_remap2: the column tiles of a row block run on CUs that share an L2).
+// The product build has no switches: constants below that read like knobs are closed A/B experiments (numbers in DESIGN.md and
+// profiles/r0*_*.txt); ablation switches (`dbg`), cycle stamps and the round-1 lockstep loop exist in -DMBX_DIAG builds only
+// (tools/build_variants.py diag).
 #include "mbx_common.h"
 #include "gelu_fast.h"
 #include <stdlib.h>
@@ -65,27 +74,13 @@ __device__ __forceinline__ uint4 epi_load_u4(const bf16_t* p) {
 }
 // measured (profiles/r03_store_policy.txt, session W): non-temporal loads of the residual -4 % on proj (0.343 -> 0.328 ms), nothing
 // on fc2; of dres / xhat in the LayerNorm-backward epilogue +0-4 %; of u in the GELU' epilogue nothing
-#ifndef MBX_LD_RES
-#define MBX_LD_RES 1
-#endif
-#ifndef MBX_LD_LNB
-#define MBX_LD_LNB 0
-#endif
-#ifndef MBX_LD_DG
-#define MBX_LD_DG 0
-#endif
-#ifndef MBX_ST_PP
-#define MBX_ST_PP 1     // bf16 store / GELU epilogue of the 256x256 kernel
-#endif
-#ifndef MBX_ST_DG
-#define MBX_ST_DG 0     // GELU' epilogue
-#endif
-#ifndef MBX_ST_RES
-#define MBX_ST_RES 0    // residual epilogue (fp32 stream)
-#endif
-#ifndef MBX_ST_LNB
-#define MBX_ST_LNB 0    // LayerNorm-backward epilogue
-#endif
+constexpr int MBX_LD_RES = 1;
+constexpr int MBX_LD_LNB = 0;
+constexpr int MBX_LD_DG = 0;
+constexpr int MBX_ST_PP = 1;   // bf16 store / GELU epilogue of the 256x256 kernel
+constexpr int MBX_ST_DG = 0;   // GELU' epilogue
+constexpr int MBX_ST_RES = 0;   // residual epilogue (fp32 stream)
+constexpr int MBX_ST_LNB = 0;   // LayerNorm-backward epilogue
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
@@ -333,9 +328,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
         const int n = n0 + wn * 64 + cc, nc = min(n, N - 8);
         // the eight passes (two 32-row halves x four) are one pipeline: the inputs of pass P + LNB_D - 1 are requested before pass P
         // is computed (clamped addresses; invalid lanes never store), across the staging of the second half as well
-#ifndef MBX_LNB_DEPTH
-#define MBX_LNB_DEPTH 2
-#endif
+constexpr int MBX_LNB_DEPTH = 2;
         constexpr int LNB_D = MBX_LNB_DEPTH;
         const int mb0 = m0 + wm * 64;
         // LNBWD_T (round 4): the gradient of the residual stream travels BETWEEN the sub-layers of a Block as bf16 -- dres arrives as
@@ -638,14 +631,8 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                         *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     } else {
                         if (out_t) *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-#if MBX_GELU_PK
                         const mbx_f32x2_t g0 = gelu_fast2(mbx_f32x2_t{v[0], v[1]}), g1 = gelu_fast2(mbx_f32x2_t{v[2], v[3]});
                         *reinterpret_cast<uint2*>(er2 + off) = make_uint2(pack_bf2(g0[0], g0[1]), pack_bf2(g1[0], g1[1]));
-#else
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-                        *reinterpret_cast<uint2*>(er2 + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-#endif
                     }
                 }
             uint4 t1[4], t2[4];   // all reads first (unpredicated), then the predicated stores: no wait per store
@@ -731,12 +718,8 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float u0 = __uint_as_float(uw[e] << 16), u1 = __uint_as_float(uw[e] & 0xffff0000u);
-#if MBX_GELU_PK
                         const mbx_f32x2_t dv_ = mbx_f32x2_t{v[2 * e], v[2 * e + 1]} * gelu_fast_grad2(mbx_f32x2_t{u0, u1});
                         r[e] = pack_bf2(dv_[0], dv_[1]);
-#else
-                        r[e] = pack_bf2(v[2 * e] * gelu_fast_grad(u0), v[2 * e + 1] * gelu_fast_grad(u1));
-#endif
                         if (st_part) {      // packed-bf16 dots (v_dot2c_f32_bf16): du . rsum and du . (u - b')
                             q1 = dot2_bf16(r[e], svp[e], q1);
                             q2 = dot2_bf16(r[e], uw[e], dot2_bf16(r[e], nbp[e], q2));
@@ -1325,12 +1308,8 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int tok0, int col0
 // the whole LDS-DMA ring once per chunk (found in round 3 by reading the ISA of the shipped gemm_tn_pipe256 loop: the
 // "three chunks in flight" were one).  An asm read is invisible to that pass; in exchange the kernel owns the lgkmcnt
 // bookkeeping: results may only be used behind an explicit s_waitcnt, and TR_TIE makes that a data dependence.
-#ifndef MBX_TR_ASM
-#define MBX_TR_ASM 1
-#endif
 template <int ROWB>
 __device__ __forceinline__ bf16x8_t tr_frag_a(const char* tile, int tok0, int col0, int lane) {
-#if MBX_TR_ASM
     const int g = lane >> 5, r16 = lane & 15, nb = col0 + 16 * ((lane >> 4) & 1) + 4 * (r16 & 3);
     const int t = tok0 + 8 * g + (r16 >> 2);
     const uint32_t a = (uint32_t)(uintptr_t)(lds_void_t*)(tile + tr_off<ROWB>(t, nb));   // rows t and t + 4 share the swizzle
@@ -1338,9 +1317,6 @@ __device__ __forceinline__ bf16x8_t tr_frag_a(const char* tile, int tok0, int co
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.h[0]) : "v"(a) : "memory");
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.h[1]) : "v"(a), "n"(4 * ROWB) : "memory");
     return f.v;
-#else
-    return tr_frag<ROWB>(tile, tok0, col0, lane);
-#endif
 }
 // `s_waitcnt <what>` as a data dependence of the six fragments of one register set (see tr_frag_a)
 #define TR_WAIT6(what_, f0, f1, f2, f3, f4, f5) \
@@ -1504,15 +1480,9 @@ static constexpr int U_BN = 256, U_BK = 256, U_BMS = 32;
 //   MBX_TN_AHEAD  chunks in flight behind the one being multiplied (3; 2 = a smaller L2 footprint per workgroup)
 //   MBX_TN_ORDER  0: the k tiles of an n panel are consecutive workgroups; 1: the n tiles of a k panel
 //   MBX_TN_AUX    cache-policy bits of the LDS-DMA loads (0 default, 2 = nt)
-#ifndef MBX_TN_AHEAD
-#define MBX_TN_AHEAD 3
-#endif
-#ifndef MBX_TN_ORDER
-#define MBX_TN_ORDER 0
-#endif
-#ifndef MBX_TN_AUX
-#define MBX_TN_AUX 0
-#endif
+constexpr int MBX_TN_AHEAD = 3;
+constexpr int MBX_TN_ORDER = 0;
+constexpr int MBX_TN_AUX = 0;
 #define GLDS16_TN(src, dst) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src), (lds_void_t*)(dst), 16, 0, MBX_TN_AUX)
 static constexpr int U_TILE = U_BMS * 512, U_STAGE = 2 * U_TILE;   // 16 KiB per operand tile, 32 KiB per stage
 
@@ -1529,12 +1499,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int split = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
     if (split >= nsplits) return;
-#if MBX_TN_ORDER == 1
-    const int ntn_ = ntiles / ntk;
-    const int n0 = (tile % ntn_) * U_BN, k0 = (tile / ntn_) * U_BK;
-#else
     const int n0 = (tile / ntk) * U_BN, k0 = (tile % ntk) * U_BK;
-#endif
     const int wr = wave >> 2, wc = wave & 3;   // wave tile: n rows [128 wr, +128), k cols [64 wc, +64)
     const int nchunks1 = (M + U_BMS - 1) / U_BMS;          // chunks of one pass
     const int nchunks = X3 ? 3 * nchunks1 : nchunks1;
@@ -1583,11 +1548,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     // dwords of step kt & 1; ntk = 1: both steps) as packed-bf16 dots with ones -- 4 (8) VALU operations per chunk in every wave of
     // every workgroup -- into its own partial slot; the slots are folded with the token splits.  (Also measured: the same dots in
     // the MFMA phase 0.602 ms -- v_dot2c beside MFMAs is expensive --, two extra ones-MFMAs per wave 0.640 ms.)
-#ifdef MBX_TN_NODB
-    const int nslot = 0;
-#else
     const int nslot = part_b == nullptr ? 0 : (ntk == 2 || ntk == 4) ? ntk : 1;       // partial slots per token split
-#endif
     const int kt_ = k0 / U_BK;
     const bool want_db = nslot > 0 && (nslot > 1 || kt_ == 0);
     const int db_s = nslot == 1 ? 0 : (kt_ & 1);                                       // this workgroup's 16-token step (nslot = 1: both)
@@ -1602,12 +1563,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     const bool trailing = wave >= 4;
     if (nc > 0) U_ISSUE(c_beg, 0);
     if (nc > 1) U_ISSUE(c_beg + 1, 1);
-#if MBX_TN_AHEAD == 3
     if (nc > 2) U_ISSUE(c_beg + 2, 2);
     if (nc > 2) WAIT_VMCNT(8); else if (nc > 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);
-#else
-    if (nc > 1) WAIT_VMCNT(4); else WAIT_VMCNT(0);
-#endif
     __builtin_amdgcn_s_barrier();
     if (trailing) __builtin_amdgcn_s_barrier();
     bf16x8_t fy[2][4], fa[2][2];
@@ -1673,15 +1630,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
         const int vc = c_beg + c;
         U_READ(stage, vc);
         // own share of chunk c+1 landed (c+2 may fly); the fragments have arrived (asm reads: nothing may touch them earlier)
-#if MBX_TN_AHEAD == 3
         if (nc - 1 - c >= 2) {
             TR_WAIT6("vmcnt(4) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
         } else {
             TR_WAIT6("vmcnt(0) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
         }
-#else
-        TR_WAIT6("vmcnt(0) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);   // only chunk c+1 is outstanding
-#endif
         TR_WAIT6("lgkmcnt(0)", fy[1][0], fy[1][1], fy[1][2], fy[1][3], fa[1][0], fa[1][1]);
         U_FIX(vc);
         U_DB_SHARE(vc);      // at the end of the read phase (behind the MFMAs of the other phase it measured the same: 0.566 vs 0.563 ms)

@@ -85,6 +85,16 @@ def crop_scale_3d_batch(motion: torch.Tensor, ratio: torch.Tensor) -> torch.Tens
     return torch.where(ok.view(-1, 1, 1, 1), out, torch.zeros_like(out))
 
 
+def shard_indices(n: int, shuffle: bool, epoch: int, seed: int, rank: int, world: int) -> np.ndarray:
+    """The clips of rank `rank` in epoch `epoch`: every rank walks the same permutation and takes a strided share, padded by
+    wrap-around to ceil(n / world) clips (what DistributedSampler does).  EQUAL shares are what keeps data-parallel ranks in
+    lock-step when the loaders of a pre-training epoch have different lengths (train.py:325-330; `pretrain_epoch_plan`): every
+    rank issues the same number of steps per loader, so the gradient all-reduces pair up."""
+    order = np.random.default_rng([seed, epoch]).permutation(n) if shuffle else np.arange(n)
+    per = -(-n // world)
+    return np.resize(order, per * world)[rank::world]
+
+
 class PackedMotion3D:
     """Memory-mapped packed clips + an asynchronous batch stream.
 
@@ -111,11 +121,7 @@ class PackedMotion3D:
         return int(self.meta['n'])
 
     def epoch_indices(self, shuffle: bool, epoch: int, seed: int, rank: int, world: int) -> np.ndarray:
-        n = len(self)
-        order = np.random.default_rng([seed, epoch]).permutation(n) if shuffle else np.arange(n)
-        per = -(-n // world)                              # equal share per rank: wrap around like DistributedSampler
-        order = np.resize(order, per * world)
-        return order[rank::world]
+        return shard_indices(len(self), shuffle, epoch, seed, rank, world)
 
     def _device_stage(self, inp, lab, gen):
         """What MotionDataset3D.__getitem__ did per clip on the host, batched on the device."""

@@ -38,18 +38,30 @@ def _mean_all_reduce(t: torch.Tensor, group, world: int):
 class _BucketSync:
     """Receives finished gradient buckets from the backward pass and all-reduces them asynchronously."""
 
-    def __init__(self, group=None, pending=None):
+    def __init__(self, group=None, pending=None, diag=None):
         self.group, self.world = group, dist.get_world_size(group)
         self.pending = pending if pending is not None else []     # shared with the wrapper's extra-parameter hooks
+        self.diag = diag                                           # optional dict (DistributedDSTformer.diagnostics)
 
     def bucket_ready(self, flat_view: torch.Tensor):
         if flat_view.numel() == 0:
             return
+        if self.diag is not None:
+            self.diag.setdefault('bucket_bytes', []).append(flat_view.numel() * flat_view.element_size())
         self.pending.append(_mean_all_reduce(flat_view, self.group, self.world))
 
     def finish(self):
+        """The compute stream waits here for the outstanding collectives.  With diagnostics on, the wait is bracketed by two events
+        on that stream: their distance is the part of the all-reduce time NOT hidden under backward ('exposed')."""
+        ev = None
+        if self.diag is not None and torch.cuda.is_available() and self.pending:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         while self.pending:
             self.pending.pop(0).wait()          # stream-level wait on GPU backends; blocks on gloo
+        if ev is not None:
+            ev[1].record()
+            self.diag.setdefault('wait_events', []).append(ev)
 
 
 class DistributedDSTformer(nn.Module):
@@ -68,6 +80,7 @@ class DistributedDSTformer(nn.Module):
             raise RuntimeError('DistributedDSTformer needs torch.distributed.init_process_group() first')
         self.module, self.group, self._ops = module, process_group, ops
         self._pending = []
+        self.diagnostics = None      # set to a dict to collect per-bucket bytes and the exposed wait of every backward (bench.py --gpus N)
         extra_params, extra_bufs = [], []
         if extra is not None:
             if isinstance(extra, nn.Module):
@@ -109,7 +122,7 @@ class DistributedDSTformer(nn.Module):
 
     def forward(self, x, return_rep: bool = False):
         from . import model as M
-        sync = _BucketSync(self.group, self._pending) if torch.is_grad_enabled() else None
+        sync = _BucketSync(self.group, self._pending, self.diagnostics) if torch.is_grad_enabled() else None
         if self._ops is None:
             self.module._check(x)
             from . import hip_ops

@@ -168,3 +168,65 @@ def test_two_rank_actionnet_head_gradients_are_synchronised():
                 assert np.allclose(res[r][1][n], p.grad.numpy(), rtol=2e-4, atol=1e-7), (n, r)
     for n in res[0][0]:
         assert np.array_equal(res[0][0][n], res[1][0][n]), f'ranks disagree on head gradient {n}'
+
+
+def _lockstep_worker(rank, world, port, q):
+    """One pre-training epoch over three loaders of DIFFERENT lengths (n clips not divisible by world x batch) on world ranks."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from motionbert_amd.data import shard_indices
+        from motionbert_amd.ddp import DistributedDSTformer
+        from motionbert_amd.train import pretrain_epoch_plan
+        from oracle.torch_ops import MockOps
+        z, cfg = load_golden('tiny_trained')
+        model = build_model(cfg, seed=300 + rank)
+        model.precision = 'fp32'
+        ddp = DistributedDSTformer(model, ops=MockOps())
+        sizes, frames, batch = dict(posetrack=7, instav=10, **{'3d': 13}), dict(posetrack=5, instav=9, **{'3d': 9}), 2
+        data = {k: make_input(n, frames[k], 17, 40 + i) for i, (k, n) in enumerate(sizes.items())}
+        counts = {k: -(-len(shard_indices(n, True, 0, 0, rank, world)) // batch) for k, n in sizes.items()}
+        steps = []
+        for loader, has_3d, has_gt, nb in pretrain_epoch_plan(counts['posetrack'], counts['instav'], counts['3d'], epoch=30):
+            idx = shard_indices(sizes[loader], True, 0, 0, rank, world)
+            for b in range(nb):
+                xb = data[loader][torch.from_numpy(idx[b * batch:(b + 1) * batch].copy())]
+                out = ddp(xb)
+                model.zero_grad(set_to_none=True)
+                ((out - xb) ** 2).mean().backward()                        # any loss: the exchange is what is tested
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.sub_(0.05 * p.grad)
+                steps.append((loader, tuple(xb.shape)))
+        q.put((rank, steps, {n: p.detach().numpy().copy() for n, p in model.named_parameters()}, sorted(np.concatenate(
+            [shard_indices(sizes['3d'], True, 0, 0, rank, world)]).tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_four_ranks_stay_in_lock_step_over_unequal_loaders():
+    """BASELINE config 4 on N ranks (SURVEY 8e gotcha 4; train.py:325-330): the three loaders of a pre-training epoch have different
+    lengths and none divides by world x batch.  Equal wrap-around shards (`shard_indices`) + one epoch plan (`pretrain_epoch_plan`)
+    make every rank issue the same steps in the same order -- the run neither dead-locks in a collective nor lets the replicas
+    drift: after the epoch the parameters of the four ranks are bit-identical, and the shards cover every clip."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lockstep_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, steps, params, idx3d = q.get(timeout=500)
+        res[r] = (steps, params, idx3d)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kinds = [[s[0] for s in res[r][0]] for r in range(world)]
+    assert all(k == kinds[0] for k in kinds), 'ranks walked different step sequences'
+    assert kinds[0] == ['posetrack'] * 1 + ['instav'] * 2 + ['3d'] * 2      # ceil(ceil(n / 4) / 2) steps per loader
+    for n in res[0][1]:
+        for r in range(1, world):
+            assert np.array_equal(res[0][1][n], res[r][1][n]), f'rank {r} drifted on {n}'
+    assert set(sum((res[r][2] for r in range(world)), [])) == set(range(13)), 'the shards do not cover the 3D loader'

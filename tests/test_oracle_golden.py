@@ -75,3 +75,21 @@ def test_oracle_matches_reference_at_baseline_config0():
             assert rel_l2(g, z['g.' + n]) < 5e-7 or ref_l2 < 1e-12, n
         else:
             assert rel_l2(g[z[f'idx.{g.size}']], z['gs.' + n]) < 5e-7, n
+
+
+@pytest.mark.parametrize('name', ['tiny_default', 'tiny_trained'])
+def test_plain_torch_restatement_matches_the_fixtures(name):
+    """oracle/torch_model.py (the CPU-baseline port of bench.py: the reference's operator mix as one plain torch function) against
+    the reference-minted fixtures: output, representation, input gradient and every parameter gradient through autograd."""
+    import torch
+    from oracle import torch_model as TM
+    z, cfg = load_golden(name)
+    P = {k[2:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith('w.')}
+    x = torch.from_numpy(z['x']).requires_grad_(True)
+    out = TM.forward(P, x, cfg['depth'], cfg['num_heads'])
+    assert rel_l2(out.detach().numpy(), z['out']) < 2e-6
+    assert rel_l2(TM.forward(P, x, cfg['depth'], cfg['num_heads'], return_rep=True).detach().numpy(), z['rep']) < 2e-6
+    (out * torch.from_numpy(z['cot'])).sum().backward()
+    assert rel_l2(x.grad.numpy(), z['dx']) < 2e-5
+    for n, p in P.items():
+        assert rel_l2(p.grad.numpy(), z['g.' + n]) < 5e-5, n
