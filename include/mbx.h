@@ -157,7 +157,9 @@ int mbx_unfold_norm_grads(float* dw, const float* db, const float* w, const floa
  * mbx_mlp_fused_fwd:   the whole MLP sub-layer of a Block (MLP.forward, DSTformer.py:79-85, inside :242 / :244 / :246 / :248)
  *     y = resid + fc2(gelu_erf(fc1(LN(.)))) in ONE kernel -- the [M, hidden] tensor never exists in HBM:
  *       a        bf16 [M,C]: raw_in = 0: the normalised operand xhat (mbx_layernorm_fwd / mbx_fuse_ln_fwd with gamma = NULL);
- *                            raw_in = 1: bf16(x) itself; mean / rstd of the row are taken in the kernel from these values
+ *                            raw_in = 1: bf16(x) itself; mean / rstd of the row are taken in the kernel from these values;
+ *                            a = NULL (raw_in = 1): the operand is bf16(resid), rounded in the kernel from the fp32 rows it loads for
+ *                            the residual anyway (no second input stream), statistics of the fp32 rows
  *       packed   the fc1 (folded) and fc2 weights in MFMA-fragment order: mbx_mlp_pack_weights(w1 bf16 [hidden,C], w2 bf16 [C,hidden])
  *                -> mbx_mlp_pack_bytes(C, hidden) bytes
  *       b1 [hidden] (folded bias b'), b2 [C], rsum [hidden] (raw_in only), resid f32 [M,C] (= x; may alias y)

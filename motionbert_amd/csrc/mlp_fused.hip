@@ -70,7 +70,7 @@ __device__ __forceinline__ u32x4_t lds_read16(unsigned base, int imm) {
 
 // Ablation switches of diagnostic builds (tools/build_variants.py name -DMBX_MLP_DBG=bits; results are wrong, timing only):
 // 1 no GELU micro-steps beside fc2, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no epilogue, 16 no MFMAs, 32 no barriers,
-// 64 no stages at all (prologue + epilogue only)
+// 64 no stages at all (prologue + epilogue only), 128 GELU micro-steps spread over all four stages of a chunk (dummy source)
 #ifndef MBX_MLP_DBG
 #define MBX_MLP_DBG 0
 #endif
@@ -165,9 +165,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     for (int k = tid; k < hidden; k += 256) { b1s[k] = b1[k]; rss[k] = raw_in ? rsum[k] : 0.f; }
     for (int k = tid; k < C; k += 256) b2s[k] = b2[k];
 
-    // ---- X: the wave's 32 rows of xhat -> LDS (wave-private image, whole 128-byte lines per DMA) -> operand fragments --------
-    char* const ximg = ring + wave * (64 * C);
-    {
+    // ---- X, the token operand of fc1, and the row constants of the raw-operand LayerNorm: fc1 = rstd acc + (b' - rstd mean rsum).
+    //   xh given, raw_in = 0: xh is the normalised operand; constants (1, 0): fc1 = 1 acc + (b' + 0 rsum).
+    //   xh given, raw_in = 1: xh = bf16 rows of the residual stream; (mean, rstd) are taken from the very values the MFMAs multiply
+    //                         (lane (i, g) holds half of row i: packed-bf16 dots with ones / with itself, halves joined across lane ^ 32).
+    //   xh == NULL:           the operand is bf16(resid) made HERE from the fp32 rows that are loaded for the accumulators anyway
+    //                         (no second input stream, 256 instead of 384 KiB of prologue loads per tile), statistics in fp32.
+    const bool from_x = xh == nullptr;             // wave-uniform (a kernel argument)
+    u32x4_t X[KS];
+    float ln_rs = 1.f, ln_k = 0.f;
+    if (!from_x) {
+        // the wave's 32 rows of xh -> LDS (wave-private image, whole 128-byte lines per DMA) -> operand fragments
+        char* const ximg = ring + wave * (64 * C);
         const int xr = lane >> 3, xp = lane & 7;
 #pragma unroll 4
         for (int j = 0; j < KS; ++j) {             // one instruction = 8 rows x 128 B: row group rb = j & 3, column segment j >> 2
@@ -175,44 +184,38 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             const int row = min(mw + 8 * rb + xr, M - 1);
             GLDS16(xh + (size_t)row * C + cs * 64 + ((xp ^ x_swz(xr, rb)) << 3), ximg + j * 1024);
         }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    u32x4_t X[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int rb = i >> 3, r = i & 7, p = 2 * (s & 3) + g;
-        X[s] = *reinterpret_cast<const u32x4_t*>(ximg + ((s >> 2) * 4 + rb) * 1024 + r * 128 + ((p ^ x_swz(r, rb)) << 4));
-    }
-    // Row constants of the raw-operand LayerNorm: fc1 = rstd acc + (b' - rstd mean rsum).  With raw_in the operand rows are bf16(y)
-    // and (mean, rstd) are taken HERE, from the very values the MFMAs will multiply (lane (i, g) holds half of row i: packed-bf16
-    // dots with ones / with itself, fp32 sums, the halves joined across lane ^ 32); otherwise the operand is already normalised
-    // and the constants are (1, 0): fc1 = 1 acc + (b' + 0 rsum).
-    float ln_rs = 1.f, ln_k = 0.f;
-    if (raw_in) {                                  // wave-uniform
-        float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            sa = dot2_bf16(X[s][0], 0x3f803f80u, sa); qa = dot2_bf16(X[s][0], X[s][0], qa);
-            sb = dot2_bf16(X[s][1], 0x3f803f80u, sb); qb = dot2_bf16(X[s][1], X[s][1], qb);
-            sa = dot2_bf16(X[s][2], 0x3f803f80u, sa); qa = dot2_bf16(X[s][2], X[s][2], qa);
-            sb = dot2_bf16(X[s][3], 0x3f803f80u, sb); qb = dot2_bf16(X[s][3], X[s][3], qb);
+            const int rb = i >> 3, r = i & 7, p = 2 * (s & 3) + g;
+            X[s] = *reinterpret_cast<const u32x4_t*>(ximg + ((s >> 2) * 4 + rb) * 1024 + r * 128 + ((p ^ x_swz(r, rb)) << 4));
         }
-        const float st = wave_halves<WaveAdd>(sa + sb), qt = wave_halves<WaveAdd>(qa + qb);
-        const float mu = st * (1.0f / (float)C);
-        ln_rs = 1.0f / sqrtf(fmaxf(qt * (1.0f / (float)C) - mu * mu, 0.f) + eps);
-        ln_k = -ln_rs * mu;
-    }
+        if (raw_in) {                              // wave-uniform
+            float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
 #pragma unroll
-    for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
+            for (int s = 0; s < KS; ++s) {
+                sa = dot2_bf16(X[s][0], 0x3f803f80u, sa); qa = dot2_bf16(X[s][0], X[s][0], qa);
+                sb = dot2_bf16(X[s][1], 0x3f803f80u, sb); qb = dot2_bf16(X[s][1], X[s][1], qb);
+                sa = dot2_bf16(X[s][2], 0x3f803f80u, sa); qa = dot2_bf16(X[s][2], X[s][2], qa);
+                sb = dot2_bf16(X[s][3], 0x3f803f80u, sb); qb = dot2_bf16(X[s][3], X[s][3], qb);
+            }
+            const float st = wave_halves<WaveAdd>(sa + sb), qt = wave_halves<WaveAdd>(qa + qb);
+            const float mu = st * (1.0f / (float)C);
+            ln_rs = 1.0f / sqrtf(fmaxf(qt * (1.0f / (float)C) - mu * mu, 0.f) + eps);
+            ln_k = -ln_rs * mu;
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // the biases are in LDS
 
     // ---- the fc2 accumulators start from residual + bias: y = x + b2 + G . W2^T is then what the MFMAs leave, and the epilogue
     // only writes.  Per 256-column half the wave's 32 residual rows arrive in its LDS image by LDS-DMA (one instruction = one row's
-    // KiB; 16-byte piece p of row r at p ^ (r & 15), applied to the source address: conflict-free both in the accumulator layout --
-    // lane (i, g): row i, piece 8 ntl + 2 qq + g -- and row-major), and each lane takes its accumulator registers from it.
+    // KiB; 16-byte piece p of row r at p ^ (r & 15), applied to the source address: conflict-free in the accumulator layout -- lane
+    // (i, g): row i, piece 8 ntl + 2 qq + g --, in the operand-fragment layout -- row i, pieces 4 s + 2 g, + 1 -- and row-major), and
+    // each lane takes its accumulator registers from it; from_x: also its operand fragments and its half of the row's statistics.
     f32x16_t acc2[NT2];
     char* const er = ring + wave * 32768;
+    float xsh = 0.f, xs1 = 0.f, xs2 = 0.f;         // from_x: shifted sums over this lane's half row
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the image's previous readers (X fragments / first half) are done
@@ -229,11 +232,37 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                 const float4 bb = *reinterpret_cast<const float4*>(b2s + nt * 32 + 8 * qq + 4 * g);
                 const float4 xv = *reinterpret_cast<const float4*>(er + i * 1024 + (((ntl * 8 + 2 * qq + g) ^ (i & 15)) << 4));
                 t[4 * qq] = xv.x + bb.x; t[4 * qq + 1] = xv.y + bb.y; t[4 * qq + 2] = xv.z + bb.z; t[4 * qq + 3] = xv.w + bb.w;
+                if (from_x) {
+                    if (hh == 0 && ntl == 0 && qq == 0) xsh = xv.x;
+                    const float d0 = xv.x - xsh, d1 = xv.y - xsh, d2 = xv.z - xsh, d3 = xv.w - xsh;
+                    xs1 += (d0 + d1) + (d2 + d3);
+                    xs2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, xs2))));
+                }
             }
             acc2[nt] = t;
             asm volatile("s_nop 1" : "+a"(acc2[nt]));             // a whole tile at a time into accumulator registers, where it stays
         }
+        if (from_x) {
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) {                     // k-steps 16 hh + sl: eight consecutive channels of row i per lane
+                const float4 lo = *reinterpret_cast<const float4*>(er + i * 1024 + (((4 * sl + 2 * g) ^ (i & 15)) << 4));
+                const float4 hi = *reinterpret_cast<const float4*>(er + i * 1024 + (((4 * sl + 2 * g + 1) ^ (i & 15)) << 4));
+                X[hh * 16 + sl] = u32x4_t{pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w)};
+            }
+        }
     }
+    if (from_x) {                                  // the row statistics: this lane's half and the partner lane's (lane ^ 32), Chan's formula
+        constexpr float nh = (float)(C / 2);
+        const float mean_h = xsh + xs1 / nh, m2_h = xs2 - xs1 * xs1 / nh;
+        const float mean_o = wave_halves<WaveAdd>(mean_h) - mean_h;
+        const float m2_both = wave_halves<WaveAdd>(m2_h);
+        const float delta = mean_o - mean_h;
+        const float var = fmaxf((m2_both + delta * delta * (nh * 0.5f)) / (float)C, 0.f);
+        ln_rs = 1.0f / sqrtf(var + eps);
+        ln_k = -ln_rs * 0.5f * (mean_h + mean_o);
+    }
+#pragma unroll
+    for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // every wave is done with its image: the ring is free
 
@@ -314,6 +343,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
 #define GE_BIAS(j_) ge_bias_ld(smem + F_RING + 16 * g + (gc * F_CH + ((j_) >> 3) * 32 + 8 * (((j_) >> 1) & 3) + 2 * ((j_) & 1)) * 4)
 #define GE_RSUM(j_) ge_bias_ld(smem + F_RING + 4 * hidden + 16 * g + (gc * F_CH + ((j_) >> 3) * 32 + 8 * (((j_) >> 1) & 3) + 2 * ((j_) & 1)) * 4)
 #define GE_LOAD(j_) do { ge_b = GE_BIAS(j_); ge_r = GE_RSUM(j_); } while (0)
+// (timing probe MBX_MLP_DBG & 128: the first eight GELU pairs run beside the fc1 stages on a dummy source -- what would spreading the
+// GELU over all four stages of a chunk buy?)
+#define GE_SRC(j_, tn_, r_) (((MBX_MLP_DBG & 128) && (j_) < 8) ? ge_dummy : acc1[tn_][r_])
+    float ge_dummy = ln_rs;
 #ifndef MBX_MLP_GELU_SCALAR
 #define MBX_MLP_GELU_SCALAR 0
 #endif
@@ -346,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     do {                                                                                                             \
         const int j_ = (ms_) >> 2, st_ = (ms_) & 3, tn_ = j_ >> 3, qq_ = (j_ >> 1) & 3, r0_ = 4 * qq_ + 2 * (j_ & 1);  /* fold after unrolling */ \
         if (st_ == 0) {                                                                                              \
-            ge_u = mbx_f32x2_t{fmaf(ln_rs, acc1[tn_][r0_], fmaf(ln_k, ge_r.x, ge_b.x)), fmaf(ln_rs, acc1[tn_][r0_ + 1], fmaf(ln_k, ge_r.y, ge_b.y))}; \
+            ge_u = mbx_f32x2_t{fmaf(ln_rs, GE_SRC(j_, tn_, r0_), fmaf(ln_k, ge_r.x, ge_b.x)), fmaf(ln_rs, GE_SRC(j_, tn_, r0_ + 1), fmaf(ln_k, ge_r.y, ge_b.y))}; \
             if (j_ + 1 < 16) GE_LOAD(j_ + 1);                     /* the next pair's constants: four slots ahead of their use */ \
             ge_a = mbx_f32x2_t{fabsf(ge_u[0]), fabsf(ge_u[1])};                                                      \
             ge_d = ge_a * 5.382975e-06f + 4.8890636e-05f;                                                            \
@@ -372,17 +405,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                             else MFMA_FC1(acc1[(k_) & 1], w_, X[16 + ((k_) >> 1)]); } while (0)
 #define HOOK_A1(k_) do { if (XL > 0 && (k_) >= 16 && (k_) < 16 + 2 * XL && !((k_) & 1)) xl[((k_) - 16) >> 1] = *reinterpret_cast<const u32x4_t*>(xsp + (((k_) - 16) >> 1) * 1024); } while (0)
 #define HOOK_NONE(k_) do { } while (0)
+#define HOOK_PA0(k_) do { if ((MBX_MLP_DBG & 128) && !((k_) & 1)) GE_STEP((k_) >> 1); } while (0)
+#define HOOK_PA1(k_) do { HOOK_A1(k_); if ((MBX_MLP_DBG & 128) && !((k_) & 1)) GE_STEP(16 + ((k_) >> 1)); } while (0)
     // fc2 slot k of the stage's part hb: k-step kk = hb KKS + k / NT2, output tile nt = k % NT2
 #define MMA_B0(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, G[(k_) / NT2])
 #define MMA_B1(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, G[KKS + (k_) / NT2])
     // GELU micro-steps beside fc2 slot k of part hb (C = 512: one per slot; C = 256: two); the first slot also pads the fc1 chain
-#define HOOK_G0(k_) do { if ((k_) == 0) MFMA_PAD_V(acc1[0], acc1[1]); if (GSTEPS == 2) { GE_STEP(2 * (k_)); GE_STEP(2 * (k_) + 1); } else GE_STEP(k_); } while (0)
-#define HOOK_G1(k_) do { GE_STEP(32 + (k_)); } while (0)
+#define HOOK_G0(k_) do { if ((k_) == 0) MFMA_PAD_V(acc1[0], acc1[1]); if (MBX_MLP_DBG & 128) { if (!((k_) & 1)) GE_STEP(32 + ((k_) >> 1)); } \
+                         else if (GSTEPS == 2) { GE_STEP(2 * (k_)); GE_STEP(2 * (k_) + 1); } else GE_STEP(k_); } while (0)
+#define HOOK_G1(k_) do { if (MBX_MLP_DBG & 128) { if (!((k_) & 1)) GE_STEP(48 + ((k_) >> 1)); } else GE_STEP(32 + (k_)); } while (0)
 
 #define MF_PART_A()                                                                                                  \
     do {                                                                                                             \
-        MF_STAGE(MMA_A0, HOOK_NONE);                                                                                 \
-        if constexpr (S2 == 2) MF_STAGE(MMA_A1, HOOK_A1);                                                            \
+        MF_STAGE(MMA_A0, HOOK_PA0);                                                                                  \
+        if constexpr (S2 == 2) MF_STAGE(MMA_A1, HOOK_PA1);                                                           \
     } while (0)
 
     // A(0), gelu(0): the only GELU that overlaps nothing
@@ -497,7 +533,8 @@ static int launch_mlp_fused(const void* a, const void* packed, const float* b1, 
 extern "C" int mbx_mlp_fused_fwd(const void* a, int raw_in, const void* packed, const float* b1, const float* b2, const float* rsum,
                                  const float* resid, float* y, void* y_t, float eps, float* mean, float* rstd, int M, int C,
                                  int hidden, void* stream) {
-    MBX_CHECK_ARG(a && packed && b1 && b2 && resid && y, "mlp_fused_fwd: null pointer");
+    MBX_CHECK_ARG(packed && b1 && b2 && resid && y, "mlp_fused_fwd: null pointer");
+    MBX_CHECK_ARG(a || raw_in, "mlp_fused_fwd: a = NULL (the operand is taken from resid) is a raw operand: raw_in must be 1");
     MBX_CHECK_ARG(M > 0 && (C == 256 || C == 512) && hidden >= F_CH && hidden % F_CH == 0 && hidden <= 1536,
                   "mlp_fused_fwd: bad shape M=%d C=%d (256 or 512) hidden=%d (%% 64, 64..1536)", M, C, hidden);
     MBX_CHECK_ARG(!raw_in || rsum, "mlp_fused_fwd: a raw operand needs rsum (row sums of the folded fc1 weights)");

@@ -24,7 +24,7 @@ modes, dropout): the fp32 input, LN mean / rstd, the normalised T-typed GEMM inp
 stored: the backward kernels recompute them from q, k and lse.
 
 No-grad sequencing (bf16, `rawln`): nothing is saved, and inside a Block no LayerNorm pass and no hidden tensor exist -- the
-residual GEMM also leaves bf16(y), the MLP is ONE kernel (mbx_mlp_fused_fwd) that normalises its raw operand itself and leaves
+MLP is ONE kernel (mbx_mlp_fused_fwd) that makes its raw operand from the fp32 rows of the residual stream itself and leaves
 bf16(y) + (mean, rstd) of its output, and the qkv GEMM applies those row constants in its epilogue (mbx_gemm_nt_rawln).
 """
 from __future__ import annotations
@@ -49,7 +49,8 @@ MODE_TEMPORAL = 1
 
 class RawRows(NamedTuple):
     """A residual-stream tensor handed to the LayerNorm -> Linear pair of the next sub-layer as a RAW operand (no-grad path):
-    t = bf16(y); mean / rstd = the LayerNorm statistics of the rows of y, or None when the consumer takes them itself."""
+    t = bf16(y), or None when the consumer (the fused MLP) rounds the fp32 rows itself; mean / rstd = the LayerNorm statistics of
+    the rows of y, or None when the consumer takes them itself."""
     t: Any
     mean: Any
     rstd: Any
@@ -396,10 +397,9 @@ class Engine:
         M, C = self.M, cfg.C
         y = self._f(M, C)
         drop = dm is not None and (dm[0] > 0 or dm[3] > 0)
-        if self.rawln and nxt is not None:      # no-grad: the next sub-layer (an MLP) takes bf16(y) as its raw operand
-            y_t = self._t(M, C)
-            ops.gemm_nt_resid_t(a, self.Wn[lin], P[lin + '.bias'], x, y, y_t)
-            return y, RawRows(y_t, None, None)
+        if self.rawln and nxt is not None:      # no-grad: the next sub-layer (an MLP) makes its raw operand from y itself
+            ops.gemm_nt(a, self.Wn[lin], P[lin + '.bias'], EPI_RESID, resid=x, out_f=y)
+            return y, RawRows(None, None, None)
         if nxt is not None and not drop and self.resid_ln:
             xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
             g, b = (None, None) if self.fold else (P[f'{pre}.{nxt}.weight'], P[f'{pre}.{nxt}.bias'])

@@ -275,7 +275,8 @@ class HipOps:
         return packed
 
     def mlp_fused_fwd(self, a_t, raw_in, packed, b1, b2, rsum, resid, y, y_t, eps, mean, rstd):
-        M, Cc = a_t.shape
+        """a_t = None: the raw operand is made in the kernel from the fp32 rows of `resid`."""
+        M, Cc = resid.shape
         self._ck(self.lib.mbx_mlp_fused_fwd(_p(a_t), int(bool(raw_in)), _p(packed), _p(b1), _p(b2), _p(rsum), _p(resid), _p(y), _p(y_t),
                                             float(eps), _p(mean), _p(rstd), M, Cc, b1.shape[0], self._stream()))
 

@@ -229,15 +229,22 @@ class MockOps:
     def mlp_fused_fwd(self, a_t, raw_in, packed, b1, b2, rsum, resid, y, y_t, eps, mean, rstd):
         """y = resid + fc2(gelu(fc1)), fc1 = a . W1^T + b1 (raw_in = 0: a is the normalised operand) or
         rstd_a (a . W1^T - mean_a rsum) + b1 with (mean_a, rstd_a) the statistics of the bf16 rows of a (raw_in = 1);
+        a_t = None: the operand is T(resid) and (mean_a, rstd_a) are the statistics of the fp32 rows of resid;
         the hidden passes through the operand type once (the kernel packs gelu(.) to bf16 for the second MFMA);
         y_t = T(y); mean / rstd = LayerNorm statistics of the rows of y."""
-        self._log('mlp_fused_fwd')
+        self._log('mlp_fused_fwd' + ('' if a_t is not None else '.from_x'))
         w1_t, w2_t = packed
+        if a_t is None:           # the operand is T(resid); the statistics are those of the fp32 rows
+            a_t = resid.to(w1_t.dtype)
+            mu = resid.mean(-1, keepdim=True)
+            rs = torch.rsqrt(((resid - mu) ** 2).mean(-1, keepdim=True) + eps)
+        elif raw_in:
+            af = a_t.float()
+            mu = af.mean(-1, keepdim=True)
+            rs = torch.rsqrt(((af * af).mean(-1, keepdim=True) - mu * mu).clamp_min(0) + eps)
         af = a_t.float()
         acc = af @ w1_t.float().t()
         if raw_in:
-            mu = af.mean(-1, keepdim=True)
-            rs = torch.rsqrt(((af * af).mean(-1, keepdim=True) - mu * mu).clamp_min(0) + eps)
             u = rs * (acc - mu * rsum) + b1
         else:
             u = acc + b1

@@ -38,8 +38,10 @@ def _mlp_case(ops, M, C, hidden, raw_in, want_t, want_stats, seed=0):
     y, y2 = mk(M, C), mk(M, C)
     yt, yt2 = (mk(M, C, dt=BF), mk(M, C, dt=BF)) if want_t else (None, None)
     (mean, rstd, mean2, rstd2) = (mk(M), mk(M), mk(M), mk(M)) if want_stats else (None,) * 4
-    ops.mlp_fused_fwd(a, raw_in, packed, b1, b2, rsum if raw_in else None, x, y, yt, eps, mean, rstd)
-    MockOps().mlp_fused_fwd(a, raw_in, (w1, w2), b1, b2, rsum, x, y2, yt2, eps, mean2, rstd2)
+    if raw_in == 2:      # the operand is made in the kernel from the fp32 rows of the residual
+        a = None
+    ops.mlp_fused_fwd(a, bool(raw_in), packed, b1, b2, rsum if raw_in else None, x, y, yt, eps, mean, rstd)
+    MockOps().mlp_fused_fwd(a, bool(raw_in), (w1, w2), b1, b2, rsum, x, y2, yt2, eps, mean2, rstd2)
     tag = f'C{C}.h{hidden}.M{M}.raw{int(raw_in)}'
     check(f'mlp_fused.branch.{tag}', y - x, y2 - x, 1e-3)
     check(f'mlp_fused.y.{tag}', y, y2, 2e-4)
@@ -56,7 +58,7 @@ def _mlp_case(ops, M, C, hidden, raw_in, want_t, want_stats, seed=0):
     return a, packed, b1, b2, rsum, x, y
 
 
-@pytest.mark.parametrize('raw_in', [0, 1])
+@pytest.mark.parametrize('raw_in', [0, 1, 2])      # 2: a = None, the operand is bf16(resid) made in the kernel
 @pytest.mark.parametrize('M,C,hidden', [(128, 512, 1024), (4131, 512, 1024), (70227, 512, 1024), (2754, 256, 1024), (389, 256, 128),
                                         (389, 512, 64), (1, 512, 1024), (129, 256, 1024)])
 def test_mlp_fused_fwd(ops, M, C, hidden, raw_in):

@@ -132,15 +132,16 @@ def test_no_grad_raw_operand_sequencing(name):
     assert rel_l2(rep.numpy(), z['rep']) < 5e-6
     depth = cfg['depth']
     # per level: 2 Blocks x (2 fused MLPs, 2 residual GEMMs that leave the raw operand, 1 qkv GEMM that consumes MLP statistics)
-    assert ops.calls.count('mlp_fused_fwd') == ops.calls.count('mlp_pack_weights') == 4 * depth
-    assert ops.calls.count('gemm_nt.resid_t') == 4 * depth and ops.calls.count('gemm_nt.rawln') == 2 * depth
-    assert ops.calls.count('gemm_nt.1') == ops.calls.count('gemm_nt.2') == 0          # no fc1 / fc2 / proj launches of the training path
+    # (the fused MLP makes its operand from the fp32 rows of the residual stream itself: its producer, proj, stays the plain residual GEMM)
+    assert ops.calls.count('mlp_fused_fwd.from_x') == ops.calls.count('mlp_pack_weights') == 4 * depth and 'mlp_fused_fwd' not in ops.calls
+    assert ops.calls.count('gemm_nt.2') == 4 * depth and ops.calls.count('gemm_nt.rawln') == 2 * depth
+    assert ops.calls.count('gemm_nt.1') == 0                                          # no fc1 (and no fc2) launches of the training path
     assert ops.calls.count('layernorm_fwd') <= 2                                      # only the two Blocks of level 0 (their input has no producer kernel)
-    assert 'mlp_fused_fwd' not in ops_plain.calls and ops_plain.calls.count('gemm_nt.1') == 4 * depth
+    assert not any(c.startswith('mlp_fused') for c in ops_plain.calls) and ops_plain.calls.count('gemm_nt.1') == 4 * depth
     # with gradients enabled the training sequencing runs, whatever the provider offers
     ops_g = MockOps()
     M.run(ops_g, model, x.clone().requires_grad_(True)).sum().backward()
-    assert 'mlp_fused_fwd' not in ops_g.calls and 'gemm_nt.rawln' not in ops_g.calls
+    assert not any(c.startswith('mlp_fused') for c in ops_g.calls) and 'gemm_nt.rawln' not in ops_g.calls
 
 
 def test_average_fusion_variant():

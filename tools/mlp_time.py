@@ -19,7 +19,8 @@ w2 = (torch.randn(C, hidden, device=dev, generator=g) * 0.05).to(BF)
 b1, b2 = torch.randn(hidden, device=dev, generator=g), torch.randn(C, device=dev, generator=g)
 rsum, packed = w1.float().sum(1), ops.mlp_pack_weights(w1, w2)
 y, yt, mean, rstd = torch.empty(M, C, device=dev), torch.empty(M, C, device=dev, dtype=BF), torch.empty(M, device=dev), torch.empty(M, device=dev)
-fn = lambda: ops.mlp_fused_fwd(a, 1, packed, b1, b2, rsum, x, y, yt, 1e-6, mean, rstd)
+from_x = os.environ.get('MLP_FROM_X', '1') == '1'      # the product's form: the operand is made from the fp32 rows in the kernel
+fn = lambda: ops.mlp_fused_fwd(None if from_x else a, 1, packed, b1, b2, rsum, x, y, yt, 1e-6, mean, rstd)
 for _ in range(3):
     fn()
 torch.cuda.synchronize()
@@ -31,5 +32,5 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 tiles = (M + 127) // 128
-print(f'{os.path.basename(os.environ.get("MBX_LIB", "libmbx.so")):28s} clips={clips} C={C}: {ms:.3f} ms = {4.0 * M * C * hidden / ms / 1e9:.0f} TF/s, '
+print(f'{os.path.basename(os.environ.get("MBX_LIB", "libmbx.so")):28s} clips={clips} C={C} {"from_x" if from_x else "bf16 operand"}: {ms:.3f} ms = {4.0 * M * C * hidden / ms / 1e9:.0f} TF/s, '
       f'{ms * 1e3 / (tiles / 256):.1f} us per tile round', flush=True)
