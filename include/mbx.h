@@ -175,6 +175,22 @@ int mbx_mlp_fused_fwd(const void* a, int raw_in, const void* packed, const float
                       const float* resid, float* y, void* y_t, float eps, float* mean, float* rstd, int M, int C, int hidden,
                       void* stream);
 
+/* ---- "row owner" NT GEMMs (bf16; csrc/gemm_rows.hip) -----------------------------------------------
+ * The same Linear layers (DSTformer.py:97 qkv, :69 fc1; the input gradients of :70 fc2 and :103 proj) on a kernel whose workgroup
+ * owns 128 complete token rows: the token operand lives in registers, the weights stream as pre-packed MFMA fragments.
+ * mbx_rows_pack_nk: w bf16 [N,K] row-major -> packed (mbx_rows_pack_bytes(N, K) bytes); K in {256, 512}, N % 64 == 0.
+ * mbx_rows_gemm_nk: out bf16 [M,N] = a . w^T + bias (bias may be NULL);  with mean != NULL the raw-operand LayerNorm form of
+ *                   mbx_gemm_nt_rawln: out = rstd[m] (a . w^T - mean[m] rsum[n]) + bias[n].
+ * mbx_rows_gemm_nk_ln: the same from the fp32 rows x [M,K] of the residual stream themselves: operand bf16(x) rounded in the kernel,
+ *                   (mean, rstd) of every row taken from the same loads (eps as in nn.LayerNorm): Linear(LayerNorm(x)) without a
+ *                   LayerNorm pass and without a bf16 copy of x (norm1 + attn.qkv of a Block, DSTformer.py:241-249 / :139-143). */
+size_t mbx_rows_pack_bytes(int N, int K);
+int mbx_rows_pack_nk(const void* w, void* packed, int N, int K, void* stream);
+int mbx_rows_gemm_nk(const void* a, const void* packed, const float* bias, const float* rsum, const float* mean, const float* rstd,
+                     void* out, int M, int N, int K, void* stream);
+int mbx_rows_gemm_nk_ln(const float* x, const void* packed, const float* bias, const float* rsum, float eps, void* out, int M, int N,
+                        int K, void* stream);
+
 /* g = gelu_erf(u), T-typed, n % 4 == 0: rebuilds the MLP's post-activation from the saved pre-activation in the engine's
  * low-memory (recompute) mode (nn.GELU, DSTformer.py:70,80-81). */
 int mbx_gelu_fwd(const void* u, void* g, size_t n, int dtype, void* stream);

@@ -23,14 +23,16 @@ qkv / o / lse (attention) or the pre-/post-GELU hidden (MLP); the fp32 sub-layer
 modes, dropout): the fp32 input, LN mean / rstd, the normalised T-typed GEMM input and the same.  Attention probabilities are never
 stored: the backward kernels recompute them from q, k and lse.
 
-No-grad sequencing (bf16, `rawln`): nothing is saved, and inside a Block no LayerNorm pass and no hidden tensor exist -- the
-MLP is ONE kernel (mbx_mlp_fused_fwd) that makes its raw operand from the fp32 rows of the residual stream itself and leaves
-bf16(y) + (mean, rstd) of its output, and the qkv GEMM applies those row constants in its epilogue (mbx_gemm_nt_rawln).
+No-grad sequencing (bf16, `rawln`): nothing is saved, and inside a Block no LayerNorm pass, no bf16 copy of the residual stream and
+no hidden tensor exist.  Both consumers of a LayerNorm read the fp32 rows of the residual stream themselves, round them to the bf16
+operand and take the row statistics from the same loads: the attention's qkv Linear as a row-owner GEMM that applies the LayerNorm
+as row constants in its epilogue (mbx_rows_gemm_nk_ln), the MLP as ONE kernel (mbx_mlp_fused_fwd).  4 launches per sub-layer pair
+(qkv, attention, proj + residual, MLP) instead of 7.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Dict, List, NamedTuple, Optional
+from typing import Any, Dict, List, Optional
 
 import os
 
@@ -45,15 +47,6 @@ EPI_DGELU = 4      # out_t  = acc * gelu'(aux_t)              (T)
 
 MODE_SPATIAL = 0
 MODE_TEMPORAL = 1
-
-
-class RawRows(NamedTuple):
-    """A residual-stream tensor handed to the LayerNorm -> Linear pair of the next sub-layer as a RAW operand (no-grad path):
-    t = bf16(y), or None when the consumer (the fused MLP) rounds the fp32 rows itself; mean / rstd = the LayerNorm statistics of
-    the rows of y, or None when the consumer takes them itself."""
-    t: Any
-    mean: Any
-    rstd: Any
 
 
 @dataclass(frozen=True)
@@ -271,6 +264,9 @@ class Engine:
                         for m in ('mlp_s', 'mlp_t'):
                             pre = f'{stream}.{i}.{m}'
                             self.Pk[pre] = ops.mlp_pack_weights(self.Wn[pre + '.fc1'], self.Wn[pre + '.fc2'])
+                        for a in ('attn_s', 'attn_t'):
+                            lin = f'{stream}.{i}.{a}.qkv'
+                            self.Pk[lin] = ops.rows_pack_nk(self.Wn[lin])
         else:
             self.Wn, self.Wt = (ops.prep_weights(P, linear_names(cfg), self.T, need_grad, x3=True) if self.x3 else
                                 ops.prep_weights(P, linear_names(cfg), self.T, need_grad))
@@ -397,9 +393,9 @@ class Engine:
         M, C = self.M, cfg.C
         y = self._f(M, C)
         drop = dm is not None and (dm[0] > 0 or dm[3] > 0)
-        if self.rawln and nxt is not None:      # no-grad: the next sub-layer (an MLP) makes its raw operand from y itself
+        if self.rawln:      # no-grad: the next sub-layer makes its operand and its LayerNorm statistics from the fp32 rows of y itself
             ops.gemm_nt(a, self.Wn[lin], P[lin + '.bias'], EPI_RESID, resid=x, out_f=y)
-            return y, RawRows(None, None, None)
+            return y, None
         if nxt is not None and not drop and self.resid_ln:
             xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
             g, b = (None, None) if self.fold else (P[f'{pre}.{nxt}.weight'], P[f'{pre}.{nxt}.bias'])
@@ -415,11 +411,11 @@ class Engine:
         M, C = self.M, cfg.C
         qkv = self._t(M, 3 * C)
         lin = f'{pre}.{attn}.qkv'
-        if isinstance(ln, RawRows) and ln.mean is not None:      # no-grad: the LayerNorm is applied in the qkv GEMM's epilogue
+        if self.rawln:      # no-grad: LayerNorm + qkv straight from the fp32 rows (operand, statistics and row constants made in the kernel)
             xn = mean = rstd = None
-            ops.gemm_nt_rawln(ln.t, self.Wn[lin], self.Bf[lin], self.Rs[lin], ln.mean, ln.rstd, qkv)
+            ops.rows_gemm_nk_ln(x, self.Pk[lin], self.Bf[lin], self.Rs[lin], cfg.eps, qkv)
         else:
-            if ln is not None and not isinstance(ln, RawRows):   # LayerNorm(x) came with x from its producer
+            if ln is not None:   # LayerNorm(x) came with x from its producer
                 xn, mean, rstd = ln
             else:
                 xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
@@ -445,20 +441,12 @@ class Engine:
     def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1, ln=None, nxt=None):
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C = self.M, cfg.C
-        if self.rawln:                # no-grad: the whole sub-layer is one kernel; the hidden never reaches HBM
+        if self.rawln:                # no-grad: the whole sub-layer is one kernel; the hidden never reaches HBM, the operand is bf16(x) made in the kernel
             lin = f'{pre}.{mlp}.fc1'
-            if isinstance(ln, RawRows):
-                a, raw = ln.t, True
-            else:
-                if ln is None:
-                    ln = (self._t(M, C), self._f(M), self._f(M))
-                    ops.layernorm_fwd(x, None, None, cfg.eps, *ln)
-                a, raw = ln[0], False
             y = self._f(M, C)
-            y_t, mean, rstd = (self._t(M, C), self._f(M), self._f(M)) if nxt is not None else (None, None, None)
-            ops.mlp_fused_fwd(a, raw, self.Pk[f'{pre}.{mlp}'], self.Bf[lin], P[f'{pre}.{mlp}.fc2.bias'], self.Rs[lin] if raw else None,
-                              x, y, y_t, cfg.eps, mean, rstd)
-            return y, None, (RawRows(y_t, mean, rstd) if nxt is not None else None)
+            ops.mlp_fused_fwd(None, True, self.Pk[f'{pre}.{mlp}'], self.Bf[lin], P[f'{pre}.{mlp}.fc2.bias'], self.Rs[lin], x, y, None,
+                              cfg.eps, None, None)
+            return y, None, None
         if ln is not None:            # LayerNorm(x) came with x from the residual GEMM of the previous sub-layer
             xn, mean, rstd = ln
         else:

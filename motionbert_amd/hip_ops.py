@@ -51,6 +51,10 @@ SIGNATURES = {
     'mbx_mlp_pack_bytes': (_sz, [_i, _i]),
     'mbx_mlp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'mbx_mlp_fused_fwd': (_i, [_vp, _i] + [_vp] * 7 + [_f, _vp, _vp, _i, _i, _i, _vp]),
+    'mbx_rows_pack_bytes': (_sz, [_i, _i]),
+    'mbx_rows_pack_nk': (_i, [_vp, _vp, _i, _i, _vp]),
+    'mbx_rows_gemm_nk': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
+    'mbx_rows_gemm_nk_ln': (_i, [_vp] * 4 + [_f, _vp, _i, _i, _i, _vp]),
     'mbx_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),
     'mbx_split_bf16': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'mbx_gemm_nt_x3': (_i, [_vp] * 5 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),
@@ -279,6 +283,26 @@ class HipOps:
         M, Cc = resid.shape
         self._ck(self.lib.mbx_mlp_fused_fwd(_p(a_t), int(bool(raw_in)), _p(packed), _p(b1), _p(b2), _p(rsum), _p(resid), _p(y), _p(y_t),
                                             float(eps), _p(mean), _p(rstd), M, Cc, b1.shape[0], self._stream()))
+
+    # ------------------------------------------------------------------ row-owner GEMMs (gemm_rows.hip)
+    def rows_pack_nk(self, w_t):
+        """w [N, K] bf16 (K in {256, 512}) -> the MFMA-fragment stream of the K-resident row-owner GEMM."""
+        N, K = w_t.shape
+        packed = torch.empty(int(self.lib.mbx_rows_pack_bytes(N, K)), dtype=torch.uint8, device=w_t.device)
+        self._ck(self.lib.mbx_rows_pack_nk(_p(w_t), _p(packed), N, K, self._stream()))
+        return packed
+
+    def rows_gemm_nk(self, a_t, packed, bias, out_t, rsum=None, mean=None, rstd=None):
+        """out_t bf16 [M,N] = a . w^T + bias, or with (rsum, mean, rstd) the raw-operand LayerNorm form of gemm_nt_rawln."""
+        M, K = a_t.shape
+        self._ck(self.lib.mbx_rows_gemm_nk(_p(a_t), _p(packed), _p(bias), _p(rsum), _p(mean), _p(rstd), _p(out_t), M, out_t.shape[1], K,
+                                           self._stream()))
+
+    def rows_gemm_nk_ln(self, x, packed, bias, rsum, eps, out_t):
+        """out_t bf16 [M,N] = Linear'(LayerNorm(x)) straight from the fp32 rows x [M,K]: operand bf16(x) and the row statistics are made
+        in the kernel (no LayerNorm pass, no bf16 copy of the residual stream)."""
+        M, K = x.shape
+        self._ck(self.lib.mbx_rows_gemm_nk_ln(_p(x), _p(packed), _p(bias), _p(rsum), float(eps), _p(out_t), M, out_t.shape[1], K, self._stream()))
 
     def gemm_nt_resid_t(self, a_t, w_t, bias, resid, y, y_t):
         M, K = a_t.shape

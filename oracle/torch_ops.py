@@ -226,6 +226,27 @@ class MockOps:
         self._log('mlp_pack_weights')
         return (w1_t, w2_t)
 
+    def rows_pack_nk(self, w_t):
+        self._log('rows_pack_nk')
+        return w_t
+
+    def rows_gemm_nk(self, a_t, packed, bias, out_t, rsum=None, mean=None, rstd=None):
+        """mbx_rows_gemm_nk: out = a . w^T + bias, or the raw-operand LayerNorm form with (rsum, mean, rstd)."""
+        self._log('rows_gemm_nk')
+        acc = a_t.float() @ packed.float().t()
+        if mean is not None:
+            acc = rstd[:, None] * (acc - mean[:, None] * rsum)
+        out_t.copy_((acc + (bias if bias is not None else 0.)).to(out_t.dtype))
+
+    def rows_gemm_nk_ln(self, x, packed, bias, rsum, eps, out_t):
+        """mbx_rows_gemm_nk_ln: Linear'(LayerNorm(x)) from the fp32 rows: operand T(x), statistics of the fp32 rows, row constants applied
+        to the accumulators: out = rstd (T(x) . w'^T - mean rsum) + b'."""
+        self._log('rows_gemm.ln')
+        mu = x.mean(-1, keepdim=True)
+        rs = torch.rsqrt(((x - mu) ** 2).mean(-1, keepdim=True) + eps)
+        acc = x.to(packed.dtype).float() @ packed.float().t()
+        out_t.copy_((rs * (acc - mu * rsum) + bias).to(out_t.dtype))
+
     def mlp_fused_fwd(self, a_t, raw_in, packed, b1, b2, rsum, resid, y, y_t, eps, mean, rstd):
         """y = resid + fc2(gelu(fc1)), fc1 = a . W1^T + b1 (raw_in = 0: a is the normalised operand) or
         rstd_a (a . W1^T - mean_a rsum) + b1 with (mean_a, rstd_a) the statistics of the bf16 rows of a (raw_in = 1);

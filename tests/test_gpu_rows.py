@@ -1,0 +1,105 @@
+"""Row-owner GEMMs (csrc/gemm_rows.hip: mbx_rows_pack_nk / mbx_rows_gemm_nk / mbx_rows_gemm_nk_ln) on a real MI355X: the qkv Linear
+behind norm1 of a Block (reference lib/model/DSTformer.py:139-143 inside Block.forward :241-249).
+
+Bars: the plain and the raw-operand form multiply the same bf16 operands in the same k order as the tile kernels and apply the same
+fp32 epilogue, so they must agree with mbx_gemm_nt / mbx_gemm_nt_rawln BIT FOR BIT; against the torch restatement
+(oracle/torch_ops.MockOps on the GPU; different summation order) bf16 outputs agree to 4e-3 relative L2.  The form that starts from
+the fp32 rows takes the LayerNorm statistics in fp32 from those rows: against the restatement 4e-3, and its statistics path is
+checked through a LayerNorm'd input with known constants."""
+import pytest
+import torch
+
+from tests.mock_ops import MockOps
+from tests.test_gpu_kernels import DEV, check, rnd
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+EPI_STORE = 0
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from motionbert_amd import hip_ops
+    return hip_ops.get()
+
+
+SHAPES = [(1000, 1536, 512), (128 * 5 + 17, 768, 256), (5, 64, 512), (4131, 1024, 512), (256, 512, 512), (33, 64, 256),
+          (2 * 243 * 17, 1536, 512)]
+
+
+def _operands(M, N, K, seed):
+    a = rnd(M, K, seed=seed, dtype=BF)
+    w = rnd(N, K, seed=seed + 1, dtype=BF, scale=0.05)
+    bias = rnd(N, seed=seed + 2, scale=0.5)
+    return a, w, bias
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_rows_gemm_store_is_the_tile_kernel_bit_for_bit(ops, M, N, K):
+    a, w, bias = _operands(M, N, K, seed=M + N)
+    packed = ops.rows_pack_nk(w)
+    out = torch.full((M, N), float('nan'), device=DEV, dtype=BF)
+    ops.rows_gemm_nk(a, packed, bias, out)
+    ref = torch.empty_like(out)
+    MockOps().rows_gemm_nk(a, w, bias, ref)
+    check(f'rows_gemm_nk.{M}x{N}x{K}', out, ref, 4e-3)
+    if N >= 256 and K % 64 == 0:      # the tile kernels' shape constraints
+        tile = torch.empty_like(out)
+        ops.gemm_nt(a, w, bias, EPI_STORE, out_t=tile)
+        assert torch.equal(out.view(torch.int16), tile.view(torch.int16)), 'row-owner and tile kernel differ'
+    # no bias: NULL is zeros
+    ops.rows_gemm_nk(a, packed, None, out)
+    MockOps().rows_gemm_nk(a, w, None, ref)
+    check(f'rows_gemm_nk.nobias.{M}x{N}x{K}', out, ref, 4e-3)
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_rows_gemm_raw_operand_layernorm(ops, M, N, K):
+    a, w, bias = _operands(M, N, K, seed=2 * M + N)
+    rsum = w.float().sum(1)
+    mean, rstd = rnd(M, seed=5, scale=0.2), rnd(M, seed=6).abs() + 0.5
+    packed = ops.rows_pack_nk(w)
+    out = torch.full((M, N), float('nan'), device=DEV, dtype=BF)
+    ops.rows_gemm_nk(a, packed, bias, out, rsum, mean, rstd)
+    ref = torch.empty_like(out)
+    MockOps().rows_gemm_nk(a, w, bias, ref, rsum, mean, rstd)
+    check(f'rows_gemm_nk.ln.{M}x{N}x{K}', out, ref, 4e-3)
+    if N >= 256 and K % 64 == 0:
+        tile = torch.empty_like(out)
+        ops.gemm_nt_rawln(a, w, bias, rsum, mean, rstd, tile)
+        assert torch.equal(out.view(torch.int16), tile.view(torch.int16)), 'row-owner and tile kernel differ'
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_rows_gemm_from_the_fp32_rows(ops, M, N, K):
+    """Linear'(LayerNorm(x)) straight from the residual stream: rows with a mean of their own and unequal scales."""
+    eps = 1e-6
+    x = rnd(M, K, seed=M + 3) * (0.5 + rnd(M, 1, seed=M + 7).abs()) + 0.7 * rnd(M, 1, seed=M + 8)
+    w = rnd(N, K, seed=M + 4, dtype=BF, scale=0.05)
+    bias = rnd(N, seed=M + 5, scale=0.5)
+    rsum = w.float().sum(1)
+    packed = ops.rows_pack_nk(w)
+    out = torch.full((M, N), float('nan'), device=DEV, dtype=BF)
+    ops.rows_gemm_nk_ln(x, packed, bias, rsum, eps, out)
+    ref = torch.empty_like(out)
+    MockOps().rows_gemm_nk_ln(x, w, bias, rsum, eps, ref)
+    check(f'rows_gemm_nk_ln.{M}x{N}x{K}', out, ref, 4e-3)
+    # the same values through the raw-operand form with statistics computed in fp64: isolates the in-kernel statistics
+    xd = x.double()
+    mu = xd.mean(-1)
+    rs = torch.rsqrt(((xd - mu[:, None]) ** 2).mean(-1) + eps)
+    two = torch.empty_like(out)
+    ops.rows_gemm_nk(x.to(BF), packed, bias, two, rsum, mu.float(), rs.float())
+    d = (out.float() - two.float()).abs()
+    ulp = two.float().abs().clamp_min(2.0 ** -6) * 2.0 ** -7      # one bf16 step at the value's magnitude
+    assert float((d / ulp).max()) <= 2.0, f'in-kernel LayerNorm statistics: {float((d / ulp).max()):.2f} bf16 steps'
+    assert float((d > 0).float().mean()) < 0.02
+
+
+def test_rows_gemm_rejects_bad_shapes(ops):
+    a, w, bias = _operands(64, 64, 128, seed=1)
+    with pytest.raises(RuntimeError):
+        ops.rows_pack_nk(w)                                  # K = 128
+    a, w, bias = _operands(64, 96, 256, seed=1)
+    with pytest.raises(RuntimeError):
+        ops.rows_pack_nk(w)                                  # N % 64
