@@ -39,6 +39,7 @@ import torch
 import torch.nn as nn
 
 FULL = dict(dim_in=3, dim_out=3, dim_feat=512, dim_rep=512, depth=5, num_heads=8, mlp_ratio=2, num_joints=17, maxlen=243)
+LITE = dict(FULL, dim_feat=256, mlp_ratio=4)     # MotionBERT-Lite (configs/pretrain/MB_lite.yaml:18-24): C = 256, hidden = 1024, head dim 32
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 
@@ -238,7 +239,7 @@ def _port_calibration():
         return None
 
 
-PMC_TABLE = next((p for p in (os.path.join(ROOT, 'profiles', f'r0{r}_pmc_bench.txt') for r in (3, 2)) if os.path.exists(p)),
+PMC_TABLE = next((p for p in (os.path.join(ROOT, 'profiles', f'r0{r}_pmc_bench.txt') for r in (4, 3, 2)) if os.path.exists(p)),
                  os.path.join(ROOT, 'profiles', 'r03_pmc_bench.txt'))
 HBM_PEAK_TBS, HBM_ACHIEVABLE_TBS = 8.0, 6.3      # MI355X_MICROARCH.md: spec / measured float4 copy
 
@@ -675,6 +676,50 @@ def main():
         opt.zero_grad(set_to_none=True)
         torch.cuda.empty_cache()
 
+    # ---- MotionBERT-Lite (the reference's second published architecture: MB_lite.yaml) at the headline batch: the same training step
+    # and the no-grad forward on the C = 256 / head-dim-32 kernels (fixtures-tested, never timed before round 4)
+    lite = None
+    if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16' and args.workload == 'pose':
+        try:
+            torch.cuda.empty_cache()
+            torch.manual_seed(1)
+            mlite = DSTformer(norm_layer=partial(nn.LayerNorm, eps=1e-6), **LITE).to(dev)
+            mlite.precision = 'bf16'
+            olite = FlatAdamW(mlite, lr=2e-4, weight_decay=0.01)
+
+            def lite_step():
+                olite.zero_grad(set_to_none=True)
+                total, _l = fused_pose_loss(mlite(x), gt, LAMBDA_SCALE, LAMBDA_VELOCITY)
+                total.backward()
+                olite.step()
+            for _ in range(2):
+                lite_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                lite_step()
+            torch.cuda.synchronize()
+            ldt = (time.perf_counter() - t1) / 5
+            mlite.eval()
+            with torch.no_grad():
+                for _ in range(2):
+                    mlite(x)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    mlite(x)
+                torch.cuda.synchronize()
+            lfd = (time.perf_counter() - t1) / 5
+            lf = model_flops_fwd(LITE, T) * B
+            lite = dict(workload=f'MotionBERT-Lite (dim_feat 256, mlp_ratio 4; 16.0 M parameters), {B} clips x {T} frames, bf16: train step (fwd + loss + bwd + AdamW) and eval + no_grad forward, 5 timed passes each after 2 warm-ups',
+                        train_ms_per_step=round(ldt * 1e3, 2), train_clips_per_s=round(B / ldt, 1), train_model_tflops=round(3.0 * lf / ldt / 1e12, 1),
+                        fwd_ms=round(lfd * 1e3, 2), fwd_clips_per_s=round(B / lfd, 1), fwd_tflops=round(lf / lfd / 1e12, 1))
+            log(f'Lite B={B}: train {ldt * 1e3:.1f} ms/step ({B / ldt:.0f} clips/s), forward only {lfd * 1e3:.2f} ms ({B / lfd:.0f} clips/s)')
+            del mlite, olite
+        except Exception as e:
+            lite = dict(error=f'{type(e).__name__}: {e}'[:300])
+        torch.cuda.empty_cache()
+
     # ---- BASELINE configs 4 and 5 at N = 1 beside the headline; `--workload pretrain|action` times them as
     # the main step (and under --gpus N), these are short samples of the same step functions
     cfg4 = cfg5 = None
@@ -758,7 +803,7 @@ def main():
                    'global_batch': B * world, 'frames': T, 'parallelism': f'dp{world}'},
         'model_tflops': round(flops_step * world / (ms * 1e-3) / 1e12, 1),
         'model_mfma_frac': round(flops_step / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS), 4),
-        'multi_gpu': multi, 'roofline': roof, 'kernel_breakdown_ms': breakdown, 'forward_only': fwd_only, 'gate_1e-3_modes': gate_modes, 'block_b256': block, 'config3_b32': cfg3, 'full_model_b256': full256, 'config4_pretrain': cfg4, 'config5_action': cfg5,
+        'multi_gpu': multi, 'roofline': roof, 'kernel_breakdown_ms': breakdown, 'forward_only': fwd_only, 'gate_1e-3_modes': gate_modes, 'block_b256': block, 'config3_b32': cfg3, 'full_model_b256': full256, 'lite_b64': lite, 'config4_pretrain': cfg4, 'config5_action': cfg5,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -41,7 +41,7 @@ for step in "$@"; do
       ( cd /tmp; rm -rf /tmp/kt; cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $CMD > gpurun_out/${TAG}_prof.log 2>&1 )
       DB=$(find /tmp/kt -name "*.db" | head -1)
       { echo "# command: MBX_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -- $CMD"; python tools/rocpd_stats.py $DB 40; } > gpurun_out/${TAG}_kernel_stats.txt
-      run() { t=$1; shift; rm -rf /tmp/pmcb; ( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --pmc "$@" -d /tmp/pmcb -o p -- $PCMD > /dev/null 2>&1 ); python tools/pmc_stats.py $(find /tmp/pmcb -name "*.db" | head -1) "" | grep -E "gemm|attn|ln_|fuse|mlp|adamw|pose|embed|head|colsum|prep|fold|rowc" > gpurun_out/pmc_bench_$t.txt; echo "pmc $t: $(wc -l < gpurun_out/pmc_bench_$t.txt) rows"; }
+      run() { t=$1; shift; rm -rf /tmp/pmcb; ( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --pmc "$@" -d /tmp/pmcb -o p -- $PCMD > /dev/null 2>&1 ); python tools/pmc_stats.py $(find /tmp/pmcb -name "*.db" | head -1) "" | grep -E "gemm|attn|ln_|fuse|mlp|rows_|adamw|pose|embed|head|colsum|prep|fold|rowc" > gpurun_out/pmc_bench_$t.txt; echo "pmc $t: $(wc -l < gpurun_out/pmc_bench_$t.txt) rows"; }
       run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
       run fetch FETCH_SIZE TCC_HIT_sum
       run write WRITE_SIZE TCC_MISS_sum
