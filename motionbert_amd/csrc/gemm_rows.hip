@@ -74,22 +74,32 @@ template <int K, int EPI, bool FROMX>
 __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict__ a, const char* __restrict__ wpk,
                                                          const float* __restrict__ bias, const float* __restrict__ rsum,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         bf16_t* __restrict__ out, float eps, int M, int N) {
+                                                         bf16_t* __restrict__ out, float eps, int M, int N, int nfull, int parts) {
     constexpr int KS = K / 16;             // k-steps = operand fragments per wave = slots per 32-column tile
     constexpr int SPC = 2 * KS / R_SL;     // stages per chunk (K = 512: 8, K = 256: 4)
     constexpr int PF = 4;                  // weight fragments in flight ahead of the MFMA that consumes them
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ring 64 KiB | 4 x 1 KiB store images | bias [N] | rsum [N]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
-    const int mw = blockIdx.x * R_BM + 32 * wave;
+    // Work units: the first `nfull` workgroups (whole rounds of the chip: 2 per CU) take one 128-row tile each and all of N; the row
+    // tiles of the last, partial round are cut into `parts` column ranges, one workgroup each, so that the round that would leave
+    // most CUs idle (64 clips: 4.03 rounds of 512 tiles) shrinks to a fraction of a tile time.
+    int tile = blockIdx.x, c0 = 0, c1 = N / R_CH;
+    if ((int)blockIdx.x >= nfull) {
+        const int r = blockIdx.x - nfull, per = c1 / parts;
+        tile = nfull + r / parts;
+        c0 = (r % parts) * per;
+        c1 = c0 + per;
+    }
+    const int mw = tile * R_BM + 32 * wave;
     // rows past M repeat row M - 1: they compute, and store, exactly that row's values (benign, and every wave issues the same
     // number of vector memory instructions -- the counted waits below depend on it)
     const int row = min(mw + i, M - 1);
     char* const ring = smem;
     float* const bs = reinterpret_cast<float*>(smem + R_RING + R_TB);
     float* const rs = bs + N;
-    const int nch = N / R_CH, NS = nch * SPC;
-    auto seq_off = [&](int qq) -> int { return min(qq, NS - 1) * R_STAGE; };   // past the end: a harmless re-read of the last stage
+    const int q0 = c0 * SPC, NS = c1 * SPC;
+    auto seq_off = [&](int qq) -> int { return min(q0 + qq, NS - 1) * R_STAGE; };   // past the end: a harmless re-read of the last stage
     // piece d (0, 1) of a stage = its fragments 4 d .. 4 d + 3, one per wave
     const unsigned wvo = wave * 1024 + lane * 16;
     const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
     // LDS image, sixteen rows per round: the 32 lanes that own the rows write their two 16-byte pieces (piece p of row r at
     // p ^ (r >> 1)), all lanes read one piece back row-major, and ONE store instruction writes sixteen 64-byte half lines (the other
     // half of a line follows 32 slots later from the chunk's second tile and meets the first in L2).
-    int ce = 0;                             // chunk of the tile being packed and stored
+    int ce = c0;                            // chunk of the tile being packed and stored
     uint32_t pkt[8];
     u32x4_t ebb = {0, 0, 0, 0}, err = {0, 0, 0, 0};             // bias / rsum of the next micro-step, read one slot ahead of their use
     u32x4_t rv = {0, 0, 0, 0};
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
 
     RS_TILE(0, false, false)                // chunk 0: tile 0 has no predecessor, the epilogue under tile 1 is the first
     RS_TILE(1, true, false)
-    for (int c = 1; c < nch; ++c) {
+    for (int c = c0 + 1; c < c1; ++c) {
         ce = c - 1;
         RS_TILE(0, true, true)              // tile 1 of the previous chunk leaves
         ce = c;
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-read tail stages have landed (nothing may arrive in LDS after the workgroup ends)
     if (MBX_ROWS_DBG & 1) return;
     asm volatile("s_nop 15" : "+v"(acc[1]));
-    ce = nch - 1;
+    ce = c1 - 1;
     RS_ELOAD(1, 0);
     RS_ESTEP(1, 0); RS_ESTEP(1, 1); RS_ESTEP(1, 2); RS_ESTEP(1, 3);
 #pragma unroll
@@ -289,8 +299,20 @@ static int launch_rows_nk(const void* a, const void* packed, const float* bias, 
     const size_t shm = R_RING + R_TB + (size_t)2 * N * sizeof(float);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(rows_nk_kernel<K, EPI, FROMX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return mbx_set_error("rows_gemm_nk: cannot reserve %zu bytes of LDS", shm);
-    hipLaunchKernelGGL((rows_nk_kernel<K, EPI, FROMX>), dim3((M + R_BM - 1) / R_BM), dim3(256), shm, s, a, (const char*)packed, bias,
-                       rsum, mean, rstd, (bf16_t*)out, eps, M, N);
+    // whole rounds of the chip (two workgroups per CU) as whole tiles; the tiles of the last, partial round in column ranges
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 2 * cus;
+    }
+    const int tiles = (M + R_BM - 1) / R_BM, nch = N / R_CH;
+    int nfull = tiles / slots * slots, parts = 1;
+    for (int pp = 8; pp > 1; --pp)
+        if (nch % pp == 0 && (tiles - nfull) * pp <= slots) { parts = pp; break; }
+    if (parts == 1) nfull = tiles;
+    hipLaunchKernelGGL((rows_nk_kernel<K, EPI, FROMX>), dim3(nfull + (tiles - nfull) * parts), dim3(256), shm, s, a, (const char*)packed, bias,
+                       rsum, mean, rstd, (bf16_t*)out, eps, M, N, nfull, parts);
     MBX_LAUNCH_CHECK("rows_gemm_nk");
     return 0;
 }
