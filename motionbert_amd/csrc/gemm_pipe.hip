@@ -1040,6 +1040,8 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
     static const int pp = mbx_env_int("MBX_NT_PP", MBX_NT_PP_DEFAULT);
 #define MBX_Q_LOCKSTEP(E)                                                                                             \
         if (!pp) {                                                                                                    \
+            if (st_part != nullptr || ln_mean != nullptr)                                                             \
+                return mbx_set_error("gemm_nt: the lockstep loop (MBX_NT_PP=0, diagnostic builds) has no row-dot / raw-operand epilogue"); \
             if (set_lds_attr(gemm_nt_pipe256_kernel<E>, shm, "gemm_nt_pipe256")) return 1;                            \
             hipLaunchKernelGGL((gemm_nt_pipe256_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w, bias, \
                                (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn);      \

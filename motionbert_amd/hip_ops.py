@@ -190,8 +190,12 @@ class HipOps:
     # ------------------------------------------------------------------ LayerNorm folding (bf16 path)
     @staticmethod
     def can_fold(tdtype, cfg) -> bool:
-        """The folded-LayerNorm kernels exist for bf16 operands; the GELU' row dots come per 64-column block."""
-        return tdtype == torch.bfloat16 and cfg.hidden % 64 == 0 and cfg.C % 8 == 0
+        """The folded-LayerNorm kernels exist for bf16 operands; every kernel-side shape constraint of the set is mirrored HERE, because
+        the decision is taken before the forward (which then drops the fp32 sub-layer inputs) and a refusal in backward would come too
+        late: GELU' row dots per 64-column block and the 64-wide k tiles of the LayerNorm-backward GEMM (hidden % 64, C % 64: K of the dX
+        GEMMs is 3 C / hidden, N is C), attention row dots only in the bf16 kernels with head dim 32 / 64 (sequence length <= 256 is a limit
+        of every attention kernel and raises in forward already)."""
+        return tdtype == torch.bfloat16 and cfg.hidden % 64 == 0 and cfg.C % 64 == 0 and cfg.hd in (32, 64)
 
     def fold_norm_weights(self, P: Dict[str, torch.Tensor], pairs, need_t: bool, tdtype=torch.bfloat16):
         """For every (linear, norm) pair: Wn[linear] = bf16(W diag(gamma)) [N,K], Wt[linear] = its transpose [K,N] (need_t),

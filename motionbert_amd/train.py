@@ -213,7 +213,14 @@ class FlatAdamW(torch.optim.Optimizer):
     Like torch.optim.AdamW, a parameter WITHOUT a gradient is skipped entirely -- no weight decay, no moment update: frozen
     layers (`partial_train`, learning.py:69-77; the reference builds its optimizer over `requires_grad` parameters only,
     train.py:284-289) and the backbone's unused `head.*` under `get_representation` keep their values bit for bit.  The
-    flat buffer is then updated range by range (one launch per contiguous run of parameters that have gradients)."""
+    flat buffer is then updated range by range (one launch per contiguous run of parameters that have gradients).
+
+    Deviation from torch.optim.AdamW, by design of the one-launch form: ONE step counter for the whole buffer (kept on the device).
+    A parameter that receives its first gradient later than the others (a layer unfrozen mid-training, `head.*` after
+    `get_representation`-only steps) gets the bias correction of the GLOBAL step, not of its own first step; `state_dict()`
+    therefore writes the global step (and zero moments) for parameters that were never updated, and `load_state_dict()` sets the
+    counter to the largest per-parameter step it finds.  The reference never unfreezes mid-run (learning.py:69-77 decides once,
+    before the optimizer is built), where the two coincide."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, ops=None):
         if isinstance(model, torch.nn.Module):
