@@ -24,6 +24,7 @@
 // and leaves fp32 partial tiles that a deterministic column-sum folds (no atomics); the bias
 // gradient (column sums of dY) rides along in the staging registers.
 #include "mbx_common.h"
+#include "lds_stream.h"
 #include <stdlib.h>
 
 template <typename T> struct GemmT;
@@ -422,6 +423,98 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ d
     }
 }
 
+// ---- fp32 weight gradient, round 4: no transposes at all.  v_mfma_f32_32x32x2_f32 takes ONE float per lane and operand: lane
+// (i, kk) holds dY[t + kk][n_i] (A operand) and A[t + kk][k_i] (B operand) -- 32 consecutive floats of a token row for the lanes of a
+// half wave, which is how the rows lie in HBM.  So the token panels go to LDS row-major exactly as they are (LDS-DMA, one
+// instruction = two token rows x 512 bytes, whole lines), an operand is a `ds_read2_b32` (both 32-column tiles of the wave at once,
+// conflict-free: 32 consecutive dwords per half wave), and the loop is 4 MFMAs of 64 cycles per two LDS instructions.  The
+// round-1 kernel above (register-staged, 4 x 4 register transposes on the way into LDS) ran at 57 TFLOP/s with 40 % LDS bank
+// conflicts and 2.3x its operand bytes in fetches; it stays for shapes that are not multiples of 128.
+//   tile 128 (n) x 128 (k), 4 waves 2 x 2, 16 tokens per stage (2 x 8 KiB), 4-stage ring = 64 KiB: two workgroups per CU.
+static constexpr int TF_BT = 16, TF_STAGE = 2 * TF_BT * 512, TF_NST = 4;
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __restrict__ dY, const float* __restrict__ A,
+                                                             float* __restrict__ part_w, float* __restrict__ part_b, int M, int N,
+                                                             int K, int ntk, int chunks_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kk = lane >> 5;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int n0 = (tile / ntk) * 128, k0 = (tile % ntk) * 128;
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool want_db = (part_b != nullptr) && (k0 == 0) && (wc == 0);
+    const int nchunks = (M + TF_BT - 1) / TF_BT;
+    const int c_beg = split * chunks_per_split, c_end = min(nchunks, c_beg + chunks_per_split);
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    if (c_beg < c_end) {
+        // this wave's four DMA instructions of a stage: instruction j = wave + 4 u: operand j >> 3 (0 dY, 1 A), token pair j & 7;
+        // lane l moves the 16-byte piece (l & 31) of token row (l >> 5) of the pair.  Tokens past M repeat row M - 1 (masked at use).
+        const unsigned ldsb = (unsigned)(uintptr_t)(const lds_void_t*)smem;
+        auto issue = [&](int chunk) {
+            const int cc = min(chunk, c_end - 1);                 // past the end: a harmless re-read, so that the wait counts stay constant
+            const unsigned st = ldsb + ((chunk - c_beg) & (TF_NST - 1)) * TF_STAGE;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = wave + 4 * u, op = j >> 3, rp = j & 7;
+                const int tok = min(cc * TF_BT + 2 * rp + kk, M - 1);
+                const float* src = op ? A + (size_t)tok * K + k0 + 4 * i : dY + (size_t)tok * N + n0 + 4 * i;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(st + op * (TF_BT * 512) + rp * 1024) : "memory");
+            }
+        };
+        issue(c_beg); issue(c_beg + 1); issue(c_beg + 2);
+        // operand reads: dword (wr 64 + i) of row (2 p + kk) of the dY panel and + 32 dwords; the same with wc in the A panel
+        const unsigned ra = ldsb + kk * 512 + (wr * 64 + i) * 4, rb = ldsb + TF_BT * 512 + kk * 512 + (wc * 64 + i) * 4;
+        typedef __attribute__((address_space(3))) const float lds_f32_t;
+        for (int c = c_beg; c < c_end; ++c) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // stage c has landed (this wave's pieces; the two stages behind it may be in flight)
+            __builtin_amdgcn_s_barrier();                         // ... everyone's; and everyone has left stage c - 1, whose slot is refilled now
+            issue(c + 3);
+            const unsigned so = ((c - c_beg) & (TF_NST - 1)) * TF_STAGE;
+            const bool ragged = (c + 1) * TF_BT > M;              // wave-uniform: only the very last chunk
+#pragma unroll
+            for (int p = 0; p < TF_BT / 2; ++p) {
+                float a0 = *reinterpret_cast<lds_f32_t*>(ra + so + p * 1024), a1 = *reinterpret_cast<lds_f32_t*>(ra + so + p * 1024 + 128);
+                const float b0 = *reinterpret_cast<lds_f32_t*>(rb + so + p * 1024), b1 = *reinterpret_cast<lds_f32_t*>(rb + so + p * 1024 + 128);
+                if (ragged && c * TF_BT + 2 * p + kk >= M) { a0 = 0.f; a1 = 0.f; }
+                if (want_db) { bsum[0] += a0; bsum[1] += a1; }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the re-read tail stages have landed: nothing arrives in LDS after the workgroup ends
+    }
+    // the partial tile: lane column = k (coalesced along k), register rows = n
+    float* pw = part_w + (size_t)split * N * K;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) {
+            const int k = k0 + wc * 64 + tc * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                pw[(size_t)n * K + k] = acc[tr][tc][r];
+            }
+        }
+    if (want_db) {     // column sums of dY: this lane's tokens (parity kk) + the other half wave's
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr) {
+            const float sum = wave_halves<WaveAdd>(bsum[tr]);
+            if (kk == 0) part_b[(size_t)split * N + n0 + wr * 64 + tr * 32 + i] = sum;
+        }
+    }
+}
+
 static int tn_splits(int M, int N, int K, int bms) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     const int nchunks = (M + bms - 1) / bms;
@@ -440,6 +533,28 @@ extern "C" size_t mbx_gemm_tn_ws(int M, int N, int K) {
     const size_t v1 = ((size_t)s * N * K + (size_t)s * N) * sizeof(float) + 256;
     const size_t v2 = mbx_gemm_tn_pipe_ws(M, N, K);
     return v1 > v2 ? v1 : v2;
+}
+static int launch_gemm_tn_f32(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, void* ws, hipStream_t s) {
+    const int ntn = N / 128, ntk = K / 128;
+    const int nchunks = (M + TF_BT - 1) / TF_BT;
+    const int splits = tn_splits(M, N, K, 32);                      // the split count the workspace was sized for
+    const int cps = (nchunks + splits - 1) / splits;
+    float* part_w = splits == 1 ? dw : (float*)ws;
+    float* part_b = db ? (splits == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TF_NST * TF_STAGE) != hipSuccess)
+            return mbx_set_error("gemm_tn: cannot reserve %d bytes of LDS", TF_NST * TF_STAGE);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(ntn * ntk, splits), dim3(256), TF_NST * TF_STAGE, s, (const float*)dy, (const float*)a, part_w,
+                       part_b, M, N, K, ntk, cps);
+    MBX_LAUNCH_CHECK("gemm_tn_f32");
+    if (splits > 1) {
+        if (mbx_launch_colsum(part_w, splits, N * K, 0, N * K, dw, s)) return 1;
+        if (db && mbx_launch_colsum(part_b, splits, N, 0, N, db, s)) return 1;
+    }
+    return 0;
 }
 template <typename T>
 static int launch_gemm_tn(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, void* ws, hipStream_t s) {
@@ -469,7 +584,9 @@ extern "C" int mbx_gemm_tn(const void* dy, const void* a, float* dw, float* db, 
         if (!mbx_use_v1_gemm()) return mbx_launch_gemm_tn_pipe(dy, a, dw, db, M, N, K, ws, s);
         return launch_gemm_tn<bf16_t>(dy, a, dw, db, M, N, K, ws, s);
     }
-    if (dtype == MBX_F32) return launch_gemm_tn<float>(dy, a, dw, db, M, N, K, ws, s);
+    if (dtype == MBX_F32)
+        return (N % 128 == 0 && K % 128 == 0 && M >= 4 * TF_BT) ? launch_gemm_tn_f32(dy, a, dw, db, M, N, K, ws, s)
+                                                               : launch_gemm_tn<float>(dy, a, dw, db, M, N, K, ws, s);
     return mbx_set_error("gemm_tn: unknown dtype %d", dtype);
 }
 

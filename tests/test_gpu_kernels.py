@@ -252,7 +252,7 @@ def test_gemm_nt_epilogues(ops, dt, M, N, K):
 
 @pytest.mark.parametrize('dt', TD)
 @pytest.mark.parametrize('M,N,K', [(306, 64, 64), (306, 192, 64), (306, 64, 128), (4131, 1536, 512), (4131, 512, 1024),
-                                   (4131, 1024, 512), (70227, 512, 512), (33, 64, 64)])
+                                   (4131, 1024, 512), (70227, 512, 512), (33, 64, 64), (1000, 128, 256), (64, 256, 128), (79, 128, 128)])
 def test_gemm_tn(ops, dt, M, N, K):
     dy, a = rnd(M, N, seed=1, dtype=dt), rnd(M, K, seed=2, dtype=dt)
     dw, db, dw2, db2 = (torch.empty(N, K, device=DEV), torch.empty(N, device=DEV), torch.empty(N, K, device=DEV),
