@@ -793,6 +793,9 @@ struct Raw4b {     // four bf16 in a uint2 -> fp32
         v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
     }
 };
+#ifndef MBX_ATTN_DBG
+#define MBX_ATTN_DBG 0      // ablation bits of diagnostic builds (timing only): 1 no compute loops, 2 no copy-out stores, 4 no tile / statistics loads, 8 no exp2 (p = 1)
+#endif
 template <int HD>
 __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                  const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
@@ -837,7 +840,7 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
         }                                                                                                  \
         sl = lse[(P.tok0 + (size_t)sr * P.tstep) * H + P.h];                                               \
     }
-    if (MBX_ATTN_STAT_EARLY) { ATTN_STAT_LOAD(); }
+    if (MBX_ATTN_STAT_EARLY && !(MBX_ATTN_DBG & 4)) { ATTN_STAT_LOAD(); }
     // ---- stage the four tiles: 16-byte chunks, all loads of a pass in flight before the first LDS store ----
     for (int i0 = tid; i0 < KP * CH; i0 += 2048) {
         uint4 v[2][4];
@@ -846,7 +849,7 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
             const int idx = i0 + u * 1024, row = idx / CH, ch = idx % CH;
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[u][t] = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < KP * CH && row < P.L) {
+            if (idx < KP * CH && row < P.L && !(MBX_ATTN_DBG & 4)) {
                 const T* r3 = qbase + (size_t)row * rstride + ch * 8;
                 v[u][0] = *reinterpret_cast<const uint4*>(r3);
                 v[u][1] = *reinterpret_cast<const uint4*>(r3 + C);
@@ -895,7 +898,7 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     const int blk = wave & 7, row = blk * 32 + (lane & 31);     // this lane's query (waves 0-7) or key (waves 8-15)
-    if (blk < nfr) {                       // L <= 256 (check_attn_args): at most eight 32-row blocks, one wave of each role per block
+    if (blk < nfr && !(MBX_ATTN_DBG & 1)) {                       // L <= 256 (check_attn_args): at most eight 32-row blocks, one wave of each role per block
         if (wave < 8) {
             // -------------------------------------------------------------- dQ   (lane = query)
             BReg<T, HD> qreg, doreg;
@@ -990,7 +993,7 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int idx = i0 + u * 1024, r = idx / CH, ch = idx % CH;
-            if (idx < KP * CH && r < P.L) {
+            if (idx < KP * CH && r < P.L && !(MBX_ATTN_DBG & 2)) {
                 T* r3 = obase3 + (size_t)r * rstride + ch * 8;
                 *reinterpret_cast<uint4*>(r3) = v[u][0];
                 *reinterpret_cast<uint4*>(r3 + C) = v[u][1];
