@@ -101,10 +101,11 @@ class TimedOps:
             r = fn(*a, **k)
             e1.record()
             flops = 0.0
+            first = lambda t: t[0] if isinstance(t, tuple) else t      # bf16x3: operands are (hi, lo) plane pairs
             if name in NT_FAMILY:
-                flops = 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]
+                flops = 2.0 * first(a[0]).shape[0] * first(a[1]).shape[0] * first(a[0]).shape[1]
             elif name == 'gemm_tn':
-                flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
+                flops = 2.0 * first(a[0]).shape[0] * first(a[0]).shape[1] * first(a[1]).shape[1]
             self.rec.append((name, flops, e0, e1))
             return r
         return wrapped

@@ -205,6 +205,15 @@ int mbx_split_bf16(const float* x, void* hi, void* lo, size_t n, void* stream); 
 int mbx_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, int epilogue,
                    float* out_t, float* out2_t, float* out_f, const float* resid, const float* aux_t, int M, int N, int K,
                    void* stream);
+/* The same with the LAST output of the epilogue written as the two bf16 planes of the operand split (hi = bf16(v), lo = bf16(v - hi),
+ * the arithmetic of mbx_split_bf16) instead of fp32 -- for outputs whose only reader is another split-operand GEMM (the MLP's
+ * activation, DSTformer.py:80-83, and its gradient): MBX_EPI_STORE (planes = out), MBX_EPI_GELU (out_t = pre-activation f32 or NULL,
+ * planes = gelu), MBX_EPI_DGELU (planes = acc * gelu'(aux_t)). */
+int mbx_gemm_nt_x3p(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, int epilogue,
+                    float* out_t, void* pl_hi, void* pl_lo, const float* aux_t, int M, int N, int K, void* stream);
+/* mbx_layernorm_fwd (T = f32) with y written as the operand planes (y_hi, y_lo bf16 [M,C]) of the Linear that follows. */
+int mbx_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float eps, void* y_hi, void* y_lo, float* mean,
+                             float* rstd, int M, int C, void* stream);
 size_t mbx_gemm_tn_x3_workspace(int M, int N, int K);
 int mbx_gemm_tn_x3(const void* dy_hi, const void* dy_lo, const void* a_hi, const void* a_lo, float* dw, float* db, int M,
                    int N, int K, void* ws, void* stream);

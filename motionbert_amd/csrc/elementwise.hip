@@ -491,7 +491,7 @@ __device__ __forceinline__ void ln_fwd_load(const float* __restrict__ x, int row
 template <typename T, int VPL, bool FULL>
 __device__ __forceinline__ void ln_fwd_row(const float4 (&raw)[VPL], const float (&g)[VPL][4], const float (&bt)[VPL][4], float eps,
                                            float invC, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                           int row, int C, int lane) {
+                                           int row, int C, int lane, bf16_t* __restrict__ y_lo = nullptr) {
     float v[VPL][4];
     float s = 0.f;
     ROW_LOOP(k) {
@@ -514,7 +514,10 @@ __device__ __forceinline__ void ln_fwd_row(const float4 (&raw)[VPL], const float
             float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = fmaf(v[k][i] * rs, g[k][i], bt[k][i]);
-            store4<T>(y + (size_t)row * C + c, o);
+            if (sizeof(T) == 4 && y_lo)      // fp32-class mode: the GEMM operand planes of the bf16x3 split instead of fp32 (y = hi plane)
+                store4_planes(reinterpret_cast<bf16_t*>(y) + (size_t)row * C + c, y_lo + (size_t)row * C + c, o);
+            else
+                store4<T>(y + (size_t)row * C + c, o);
         }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -522,7 +525,8 @@ __device__ __forceinline__ void ln_fwd_row(const float4 (&raw)[VPL], const float
 template <typename T, int VPL, bool FULL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int C) {
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
+                                                     bf16_t* __restrict__ y_lo) {
     const int lane = threadIdx.x & 63;
     float g[VPL][4], bt[VPL][4];
     ROW_LOOP(k) {
@@ -541,15 +545,26 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         float4 ra[VPL], rb[VPL];
         ln_fwd_load<VPL, FULL>(x, row0, C, lane, ra);
         if (row1 < M) ln_fwd_load<VPL, FULL>(x, row1, C, lane, rb);
-        ln_fwd_row<T, VPL, FULL>(ra, g, bt, eps, invC, y, mean, rstd, row0, C, lane);
-        if (row1 < M) ln_fwd_row<T, VPL, FULL>(rb, g, bt, eps, invC, y, mean, rstd, row1, C, lane);
+        ln_fwd_row<T, VPL, FULL>(ra, g, bt, eps, invC, y, mean, rstd, row0, C, lane, y_lo);
+        if (row1 < M) ln_fwd_row<T, VPL, FULL>(rb, g, bt, eps, invC, y, mean, rstd, row1, C, lane, y_lo);
     }
 }
 #define LN_FWD_LAUNCH(TT, FULLV)                                                                                             \
     DISPATCH_VPL(vpl, hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL, FULLV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (TT*)y, \
-                                         mean, rstd, M, C))
+                                         mean, rstd, M, C, (bf16_t*)y_lo))
+static int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* y, void* y_lo, float* mean,
+                                float* rstd, int M, int C, int dtype, void* stream);
 extern "C" int mbx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
                                  float* rstd, int M, int C, int dtype, void* stream) {
+    return launch_layernorm_fwd(x, gamma, beta, eps, y, nullptr, mean, rstd, M, C, dtype, stream);
+}
+extern "C" int mbx_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float eps, void* y_hi, void* y_lo,
+                                        float* mean, float* rstd, int M, int C, void* stream) {
+    MBX_CHECK_ARG(y_lo, "layernorm_fwd_planes: null pointer");
+    return launch_layernorm_fwd(x, gamma, beta, eps, y_hi, y_lo, mean, rstd, M, C, MBX_F32, stream);
+}
+static int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, void* y, void* y_lo, float* mean,
+                                float* rstd, int M, int C, int dtype, void* stream) {
     MBX_CHECK_ARG(x && y && mean && rstd, "layernorm_fwd: null pointer");
     MBX_CHECK_ARG((gamma && beta) || (!gamma && !beta), "layernorm_fwd: gamma and beta come together (both NULL = plain normalisation)");
     MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "layernorm_fwd: bad shape M=%d C=%d", M, C);

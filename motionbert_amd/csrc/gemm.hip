@@ -619,6 +619,15 @@ extern "C" int mbx_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_
     }
     return mbx_launch_gemm_nt_x3(a_hi, a_lo, w_hi, w_lo, bias, epilogue, out_t, out2_t, out_f, resid, aux_t, M, N, K, (hipStream_t)stream);
 }
+extern "C" int mbx_gemm_nt_x3p(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, int epilogue,
+                               float* out_t, void* pl_hi, void* pl_lo, const float* aux_t, int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(a_hi && a_lo && w_hi && w_lo && pl_hi && pl_lo, "gemm_nt_x3p: null operand / plane");
+    MBX_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 64 == 0, "gemm_nt_x3p: bad shape M=%d N=%d K=%d (N %% 8, K %% 64)", M, N, K);
+    MBX_CHECK_ARG(epilogue == MBX_EPI_STORE || epilogue == MBX_EPI_GELU || epilogue == MBX_EPI_DGELU, "gemm_nt_x3p: epilogue %d has no plane output", epilogue);
+    MBX_CHECK_ARG(epilogue != MBX_EPI_DGELU || aux_t, "gemm_nt_x3p: DGELU needs aux_t");
+    return mbx_launch_gemm_nt_x3(a_hi, a_lo, w_hi, w_lo, bias, epilogue, out_t, nullptr, nullptr, nullptr, aux_t, M, N, K, (hipStream_t)stream,
+                                 pl_hi, pl_lo);
+}
 extern "C" size_t mbx_gemm_tn_x3_workspace(int M, int N, int K) { return mbx_gemm_tn_x3_ws(M, N, K); }
 extern "C" int mbx_gemm_tn_x3(const void* dy_hi, const void* dy_lo, const void* a_hi, const void* a_lo, float* dw, float* db, int M,
                               int N, int K, void* ws, void* stream) {

@@ -507,7 +507,10 @@ template <int EPI, int NTN, typename TO = bf16_t>
 __device__ __forceinline__ void nt_epilogue(f32x16_t (&acc)[NTN][4], char* er, const float* __restrict__ bias,
                                             TO* __restrict__ out_t, TO* __restrict__ out2_t, float* __restrict__ out_f,
                                             const float* __restrict__ resid, const TO* __restrict__ aux, int M, int N,
-                                            int row_base, int col_base, int lane) {
+                                            int row_base, int col_base, int lane, bf16_t* __restrict__ pl_hi = nullptr,
+                                            bf16_t* __restrict__ pl_lo = nullptr) {
+    // pl_hi / pl_lo (fp32-class mode only): the LAST output of the epilogue (STORE: out, GELU: the activation, DGELU: the gradient)
+    // leaves as the two bf16 planes of the bf16x3 operand split instead of fp32 -- its only reader is a split-operand GEMM
     const int i = lane & 31, g = lane >> 5;
     constexpr int EROW = 64 * 4 + 16;
     const int ec = (lane & 15) * 4, erow0 = lane >> 4;
@@ -543,12 +546,14 @@ __device__ __forceinline__ void nt_epilogue(f32x16_t (&acc)[NTN][4], char* er, c
                     float v[4] = {t4.x + bb[0], t4.y + bb[1], t4.z + bb[2], t4.w + bb[3]};
                     const size_t o = (size_t)m * N + n;
                     if (EPI == MBX_EPI_STORE) {
-                        store4<TO>(out_t + o, v);
+                        if (sizeof(TO) == 4 && pl_hi) store4_planes(pl_hi + o, pl_lo + o, v);
+                        else store4<TO>(out_t + o, v);
                     } else if (EPI == MBX_EPI_GELU) {
                         if (out_t) store4<TO>(out_t + o, v);   // pre-activation is only needed for backward
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = sizeof(TO) == 4 ? gelu_erf(v[e]) : gelu_fast(v[e]);
-                        store4<TO>(out2_t + o, v);
+                        if (sizeof(TO) == 4 && pl_hi) store4_planes(pl_hi + o, pl_lo + o, v);
+                        else store4<TO>(out2_t + o, v);
                     } else if (EPI == MBX_EPI_RESID) {
                         v[0] += rr[p].x; v[1] += rr[p].y; v[2] += rr[p].z; v[3] += rr[p].w;
                         store4<float>(out_f + o, v);
@@ -561,7 +566,8 @@ __device__ __forceinline__ void nt_epilogue(f32x16_t (&acc)[NTN][4], char* er, c
                         load4<TO>(aux + o, u);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= sizeof(TO) == 4 ? gelu_erf_grad(u[e]) : gelu_fast_grad(u[e]);
-                        store4<TO>(out_t + o, v);
+                        if (sizeof(TO) == 4 && pl_hi) store4_planes(pl_hi + o, pl_lo + o, v);
+                        else store4<TO>(out_t + o, v);
                     }
                 }
             }
@@ -746,12 +752,13 @@ __device__ __forceinline__ void nt256_epilogue(f32x16_t (&acc)[2][4], char* smem
                                                const float* __restrict__ resid, const TO* __restrict__ aux, int M, int N, int m0,
                                                int n0, int wave, int lane, const float* __restrict__ st_bias = nullptr,
                                                const float* __restrict__ st_rsum = nullptr, float* __restrict__ st_part = nullptr,
-                                               const float* __restrict__ ln_mean = nullptr, const float* __restrict__ ln_rstd = nullptr) {
+                                               const float* __restrict__ ln_mean = nullptr, const float* __restrict__ ln_rstd = nullptr,
+                                               bf16_t* __restrict__ pl_hi = nullptr, bf16_t* __restrict__ pl_lo = nullptr) {
     __builtin_amdgcn_s_barrier();   // every wave is done with the k-loop's LDS stages
     char* er = smem + wave * Q_EPI_WAVE_BYTES;
     const int row_base = m0 + (wave >> 2) * 128, col_base = n0 + (wave & 3) * 64;
     if constexpr (sizeof(TO) == 4) {      // fp32-class mode (bf16x3): every T-typed tensor is fp32
-        nt_epilogue<EPI, 2, TO>(acc, er, bias, out_t, out2_t, out_f, resid, aux, M, N, row_base, col_base, lane);
+        nt_epilogue<EPI, 2, TO>(acc, er, bias, out_t, out2_t, out_f, resid, aux, M, N, row_base, col_base, lane, pl_hi, pl_lo);
     } else if constexpr (EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU || EPI == MBX_EPI_STORE_LN) {
         if (row_base + 128 <= M && col_base + 64 <= N)
             nt_epilogue_bf16<EPI, 2, true>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane, st_rsum, ln_mean, ln_rstd);
@@ -871,7 +878,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
                                                                int M, int N, int K, int ntn,
                                                                const float* __restrict__ st_bias, const float* __restrict__ st_rsum,
                                                                float* __restrict__ st_part, const float* __restrict__ ln_mean,
-                                                               const float* __restrict__ ln_rstd
+                                                               const float* __restrict__ ln_rstd, bf16_t* __restrict__ pl_hi,
+                                                               bf16_t* __restrict__ pl_lo
 #ifdef MBX_DIAG
                                                                , long long* trace      // cycle stamps: diagnostic builds only
 #endif
@@ -1011,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
 #undef PSTAMP
     if (!trailing) __builtin_amdgcn_s_barrier();   // pairs with the trailing group's last phase
 
-    nt256_epilogue<EPI, TO>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane, st_bias, st_rsum, st_part, ln_mean, ln_rstd);
+    nt256_epilogue<EPI, TO>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane, st_bias, st_rsum, st_part, ln_mean, ln_rstd, pl_hi, pl_lo);
 #ifdef MBX_DIAG
     if (trace != nullptr && blockIdx.x == 3000 && (tid == 0 || tid == 256)) {
         long long* const tr2 = trace + (tid == 256 ? 2048 : 0);
@@ -1060,7 +1068,7 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w,        \
                            (const bf16_t*)nullptr, (const bf16_t*)nullptr, bias,                                      \
                            (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn,          \
-                           st_bias, st_rsum, st_part, ln_mean, ln_rstd MBX_Q_TRACE_ARG);                              \
+                           st_bias, st_rsum, st_part, ln_mean, ln_rstd, (bf16_t*)nullptr, (bf16_t*)nullptr MBX_Q_TRACE_ARG); \
         break;
     switch (epi) {
         MBX_Q_CASE(MBX_EPI_STORE)
@@ -1081,7 +1089,7 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
 // fp32-class split-operand GEMM (precision 'bf16x3'): always the 256 x 256 ping-pong kernel; T-typed tensors are fp32
 int mbx_launch_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, int epi,
                           float* out_t, float* out2_t, float* out_f, const float* resid, const float* aux, int M, int N, int K,
-                          hipStream_t s) {
+                          hipStream_t s, void* pl_hi, void* pl_lo) {
     const int ntn = (N + Q_BN - 1) / Q_BN, ntm = (M + Q_BM - 1) / Q_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
     const size_t shm = Q_NSTAGE * Q_STAGE;
@@ -1096,7 +1104,7 @@ int mbx_launch_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_hi, 
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E, true>), grid, block, shm, s, (const bf16_t*)a_hi, (const bf16_t*)w_hi, \
                            (const bf16_t*)a_lo, (const bf16_t*)w_lo, bias, out_t, out2_t, out_f, resid, aux, M, N, K, ntn, \
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const float*)nullptr,      \
-                           (const float*)nullptr MBX_X3_TRACE_ARG);                                                   \
+                           (const float*)nullptr, (bf16_t*)pl_hi, (bf16_t*)pl_lo MBX_X3_TRACE_ARG);                   \
         break;
     switch (epi) {
         MBX_X3_CASE(MBX_EPI_STORE)

@@ -80,6 +80,15 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
 }
+// the bf16x3 operand split of four fp32 values, written where a producer would otherwise leave fp32 for mbx_split_bf16 to read again:
+// hi = bf16(v), lo = bf16(v - hi) (the arithmetic of split_bf16_kernel, bit for bit)
+__device__ __forceinline__ void store4_planes(bf16_t* hi, bf16_t* lo, const float (&v)[4]) {
+    float h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = bf2f(f2bf(v[e])); l[e] = v[e] - h[e]; }
+    store4<bf16_t>(hi, h);
+    store4<bf16_t>(lo, l);
+}
 
 // ---------------------------------------------------------------- wave-level reductions (64 lanes)
 // VALU-only reduction: four DPP butterfly steps inside each 16-lane row (quad_perm xor 1, xor 2, row_half_mirror,
@@ -152,7 +161,7 @@ size_t mbx_gemm_tn_pipe_ws(int M, int N, int K);
 int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, void* ws, hipStream_t s);
 int mbx_launch_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, int epi,
                           float* out_t, float* out2_t, float* out_f, const float* resid, const float* aux, int M, int N, int K,
-                          hipStream_t s);
+                          hipStream_t s, void* pl_hi = nullptr, void* pl_lo = nullptr);
 size_t mbx_gemm_tn_x3_ws(int M, int N, int K);
 int mbx_launch_gemm_tn_x3(const void* dy_hi, const void* dy_lo, const void* a_hi, const void* a_lo, float* dw, float* db, int M, int N,
                           int K, void* ws, hipStream_t s);

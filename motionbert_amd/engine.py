@@ -139,6 +139,7 @@ class Engine:
         # precision 'bf16x3': T-typed tensors are fp32; a tensor that feeds a GEMM is split into (hi, lo) bf16 planes first
         # (`_mm`), and where it ONLY feeds GEMMs (LayerNorm output, GELU output) the planes are what is kept for backward
         self.x3 = x3
+        self.x3_planes = os.environ.get('MBX_X3_PLANES', '1') == '1' and hasattr(ops, 'layernorm_fwd_planes_ok')      # A/B switch: 0 = every operand through mbx_split_bf16
         self.Wn: Dict[str, torch.Tensor] = {}
         self.Wt: Dict[str, torch.Tensor] = {}
         # The st and ts blocks of a level are independent (DSTformer.py:341-342 feeds both the same x): with
@@ -239,13 +240,20 @@ class Engine:
         if sv['xn'] is not None:
             return sv['xn']
         cfg, P = self.cfg, self.P
-        xn, mean, rstd = self._t(self.M, cfg.C), self._f(self.M), self._f(self.M)
+        xn, mean, rstd = self._op(self.M, cfg.C), self._f(self.M), self._f(self.M)
         self.ops.layernorm_fwd(sv['x'], P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
         return self._mm(xn)
 
     def _mm(self, t):
-        """GEMM operand form of a T-typed tensor: itself, or its (hi, lo) bf16 planes in bf16x3 mode."""
-        return self.ops.split(t) if self.x3 else t
+        """GEMM operand form of a T-typed tensor: itself, or its (hi, lo) bf16 planes in bf16x3 mode (already planes: unchanged)."""
+        return self.ops.split(t) if self.x3 and not isinstance(t, tuple) else t
+
+    def _op(self, *shape):
+        """A tensor that is ONLY read as a GEMM operand: T-typed, or -- bf16x3 -- the pair of bf16 planes its producer writes directly
+        (no fp32 copy for mbx_split_bf16 to read again)."""
+        if self.x3 and self.x3_planes:
+            return (torch.empty(shape, dtype=torch.bfloat16, device=self.dev), torch.empty(shape, dtype=torch.bfloat16, device=self.dev))
+        return self._t(*shape)
 
     def prepare_weights(self, need_grad: bool):
         """T-typed copies of every Linear weight (and their transposes when a backward follows); with LayerNorm folding the
@@ -346,7 +354,7 @@ class Engine:
         if ln_tail is not None:
             xn, mean, rstd = ln_tail
         else:
-            xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+            xn, mean, rstd = self._op(M, C), self._f(M), self._f(M)
             ops.layernorm_fwd(h, P['norm.weight'], P['norm.bias'], cfg.eps, xn, mean, rstd)
         xn = self._mm(xn)
         # the returned tensor is allocated in its final 4-D shape (the kernels see [M, .] views of it): autograd refuses
@@ -418,7 +426,7 @@ class Engine:
             if ln is not None:   # LayerNorm(x) came with x from its producer
                 xn, mean, rstd = ln
             else:
-                xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+                xn, mean, rstd = self._op(M, C), self._f(M), self._f(M)
                 if self.fold:
                     ops.layernorm_fwd(x, None, None, cfg.eps, xn, mean, rstd)
                 else:
@@ -450,16 +458,18 @@ class Engine:
         if ln is not None:            # LayerNorm(x) came with x from the residual GEMM of the previous sub-layer
             xn, mean, rstd = ln
         else:
-            xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
+            xn, mean, rstd = self._op(M, C), self._f(M), self._f(M)
             if self.fold:
                 ops.layernorm_fwd(x, None, None, cfg.eps, xn, mean, rstd)
             else:
                 ops.layernorm_fwd(x, P[f'{pre}.{norm}.weight'], P[f'{pre}.{norm}.bias'], cfg.eps, xn, mean, rstd)
         xn = self._mm(xn)
-        u, g = (self._t(M, cfg.hidden) if need_grad else None), self._t(M, cfg.hidden)   # u only feeds GELU' in backward
+        dm = self._drops(pre, sub)
+        mlp_drop = dm is not None and dm[0] > 0
+        # u only feeds GELU' in backward; g is only fc2's operand (and the weight gradient's) unless the MLP dropout touches it first
+        u, g = (self._t(M, cfg.hidden) if need_grad else None), (self._t(M, cfg.hidden) if mlp_drop else self._op(M, cfg.hidden))
         ops.gemm_nt(xn, self.Wn[f'{pre}.{mlp}.fc1'], self.Bf[f'{pre}.{mlp}.fc1'] if self.fold else P[f'{pre}.{mlp}.fc1.bias'],
                     EPI_GELU, out_t=u, out2_t=g)
-        dm = self._drops(pre, sub)
         if dm is not None and dm[0] > 0:                      # MLP drop after the activation (DSTformer.py:82)
             ops.dropout(g, g, dm[0], dm[2])
         g = self._mm(g)
@@ -670,6 +680,8 @@ class Engine:
             part = self._f(cfg.hidden // 64, M, 2)
             ops.gemm_nt_dgelu_stats(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], du, sv['u'], self.Bf[lin], self.Rs[lin], part)
             return self._fold_tail(du, part, sv, lin, f'{pre}.{norm}', dy, dy_t, extra, need_t)
+        if self.x3 and not (dm is not None and dm[0] > 0):
+            du = self._op(M, cfg.hidden)                      # bf16x3: the GELU' epilogue writes the operand planes itself
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], None, EPI_DGELU, out_t=du, aux_t=sv['u'])
         if dm is not None and dm[0] > 0:                      # backward of the drop after the activation (commutes with GELU')
             ops.dropout(du, du, dm[0], dm[2])

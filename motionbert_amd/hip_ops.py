@@ -57,6 +57,8 @@ SIGNATURES = {
     'mbx_rows_gemm_nk_ln': (_i, [_vp] * 4 + [_f, _vp, _i, _i, _i, _vp]),
     'mbx_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),
     'mbx_split_bf16': (_i, [_vp, _vp, _vp, _sz, _vp]),
+    'mbx_gemm_nt_x3p': (_i, [_vp] * 5 + [_i] + [_vp] * 4 + [_i, _i, _i, _vp]),
+    'mbx_layernorm_fwd_planes': (_i, [_vp] * 3 + [_f] + [_vp] * 4 + [_i, _i, _vp]),
     'mbx_gemm_nt_x3': (_i, [_vp] * 5 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),
     'mbx_gemm_tn_x3_workspace': (_sz, [_i, _i, _i]),
     'mbx_gemm_tn_x3': (_i, [_vp] * 6 + [_i, _i, _i, _vp, _vp]),
@@ -366,8 +368,14 @@ class HipOps:
                                         _p(ws), self._stream()))
 
     # ------------------------------------------------------------------ layernorm
+    layernorm_fwd_planes_ok = True      # the producers below accept a (hi, lo) pair of bf16 planes where a bf16x3 GEMM operand is due
+
     def layernorm_fwd(self, x, g, b, eps, y_t, mean, rstd):
         M, Cc = x.shape
+        if isinstance(y_t, tuple):      # bf16x3: the operand planes straight from the kernel
+            self._ck(self.lib.mbx_layernorm_fwd_planes(_p(x), _p(g), _p(b), float(eps), _p(y_t[0]), _p(y_t[1]), _p(mean), _p(rstd), M, Cc,
+                                                       self._stream()))
+            return
         self._ck(self.lib.mbx_layernorm_fwd(_p(x), _p(g), _p(b), float(eps), _p(y_t), _p(mean), _p(rstd), M, Cc,
                                             _DT[y_t.dtype], self._stream()))
 
@@ -394,6 +402,11 @@ class HipOps:
             N = wh.shape[0]
             if wh.shape[1] != K:
                 raise RuntimeError(f'libmbx: gemm_nt_x3 operand mismatch {tuple(ah.shape)} x {tuple(wh.shape)}')
+            planes = out2_t if isinstance(out2_t, tuple) else (out_t if isinstance(out_t, tuple) else None)
+            if planes is not None:       # the last output leaves as the (hi, lo) planes of the operand split
+                self._ck(self.lib.mbx_gemm_nt_x3p(_p(ah), _p(al), _p(wh), _p(wl), _p(bias), int(epi), _p(None if planes is out_t else out_t),
+                                                  _p(planes[0]), _p(planes[1]), _p(aux_t), M, N, K, self._stream()))
+                return
             self._ck(self.lib.mbx_gemm_nt_x3(_p(ah), _p(al), _p(wh), _p(wl), _p(bias), int(epi), _p(out_t), _p(out2_t), _p(out_f),
                                              _p(resid), _p(aux_t), M, N, K, self._stream()))
             return

@@ -150,7 +150,14 @@ class MockOps:
         mean.copy_(mu)
         rstd.copy_(rs)
         xhat = (x - mu[:, None]) * rs[:, None]
-        y_t.copy_((xhat if g is None else xhat * g + b).to(y_t.dtype))     # g = b = None: plain normalisation
+        y = xhat if g is None else xhat * g + b                             # g = b = None: plain normalisation
+        if isinstance(y_t, tuple):      # bf16x3: the operand planes straight from the kernel
+            self._log('planes')
+            hi, lo = self.split(y)
+            y_t[0].copy_(hi)
+            y_t[1].copy_(lo)
+        else:
+            y_t.copy_(y.to(y_t.dtype))
 
     def layernorm_bwd(self, dy_t, x, mean, rstd, g, dres, extra, dx, dx_t, dg, db):
         """dx = [dres] + [extra] + LN'(dy); dx_t = T copy of dx; dg, db reduced over rows."""
@@ -180,21 +187,30 @@ class MockOps:
             acc = a_t.float() @ w_t.float().t()
         if bias is not None:
             acc = acc + bias
+        def put(dst, v):      # a T-typed output, or (bf16x3) the pair of operand planes the epilogue writes instead of fp32
+            if isinstance(dst, tuple):
+                self._log('planes')
+                hi, lo = self.split(v)
+                dst[0].copy_(hi)
+                dst[1].copy_(lo)
+            else:
+                dst.copy_(v.to(dst.dtype))
         if epi == EPI_STORE:
-            out_t.copy_(acc.to(out_t.dtype))
+            put(out_t, acc)
         elif epi == EPI_GELU:
             if out_t is not None:
                 out_t.copy_(acc.to(out_t.dtype))
-            out2_t.copy_(F.gelu(acc).to(out2_t.dtype))   # gelu of the fp32 value, as the kernel epilogue does
+            put(out2_t, F.gelu(acc))   # gelu of the fp32 value, as the kernel epilogue does
         elif epi == EPI_RESID:
             out_f.copy_(resid + acc)
         elif epi == EPI_TANH:
             out_f.copy_(torch.tanh(acc))
         elif epi == EPI_DGELU:
-            out_t.copy_((acc * _gelu_grad(aux_t.float())).to(out_t.dtype))
+            put(out_t, acc * _gelu_grad(aux_t.float()))
         else:
             raise ValueError(epi)
 
+    layernorm_fwd_planes_ok = True      # producers accept a (hi, lo) pair where a bf16x3 GEMM operand is due
     fuse_resid_ln = True      # tests switch it off to exercise the unfused sequencing
     grad_stream_t = True      # gemm_nt_lnbwd takes a T-typed dres and may skip the fp32 dx (the gradient stream inside a Block)
 

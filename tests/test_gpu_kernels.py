@@ -299,6 +299,39 @@ def test_gemm_nt_x3(ops, M, N, K):
     ops.gemm_nt((ah, al), wp, None, EPI_DGELU, out_t=d, aux_t=aux)
     MockOps().gemm_nt((ah, al), wp, None, EPI_DGELU, out_t=d2, aux_t=aux)
     check(f'gemm_nt_x3.dgelu.{M}x{N}x{K}', d, d2, 2e-5)
+    # the same outputs as operand planes straight from the epilogue: bit for bit the split of the fp32 output
+    BF = torch.bfloat16
+    pl = lambda: (torch.full((M, N), float('nan'), device=DEV, dtype=BF), torch.full((M, N), float('nan'), device=DEV, dtype=BF))
+    same = lambda p, t: all(torch.equal(x.view(torch.int16), y.view(torch.int16)) for x, y in zip(p, ops.split(t)))
+    p = pl()
+    ops.gemm_nt((ah, al), wp, bias, EPI_STORE, out_t=p)
+    assert same(p, out), 'store planes'
+    p, u3 = pl(), torch.empty(M, N, device=DEV)
+    ops.gemm_nt((ah, al), wp, bias, EPI_GELU, out_t=u3, out2_t=p)
+    assert same(p, g) and torch.equal(u3, u), 'gelu planes'
+    p = pl()
+    ops.gemm_nt((ah, al), wp, bias, EPI_GELU, out_t=None, out2_t=p)
+    assert same(p, g), 'gelu planes without the pre-activation'
+    p = pl()
+    ops.gemm_nt((ah, al), wp, None, EPI_DGELU, out_t=p, aux_t=aux)
+    assert same(p, d), 'dgelu planes'
+
+
+@pytest.mark.parametrize('M,C', [(306, 64), (4131, 512), (1000, 256), (77, 1024)])
+@pytest.mark.parametrize('affine', [False, True])
+def test_layernorm_fwd_planes(ops, M, C, affine):
+    """mbx_layernorm_fwd_planes: the bf16x3 operand planes of LayerNorm(x) = the split of the fp32 kernel's output, bit for bit."""
+    x = rnd(M, C, seed=1) * 2.0 + 0.3
+    g, b = (rnd(C, seed=2) * 0.2 + 1.0, rnd(C, seed=3) * 0.1) if affine else (None, None)
+    y, mean, rstd = torch.empty(M, C, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x, g, b, 1e-6, y, mean, rstd)
+    BF = torch.bfloat16
+    p = (torch.full((M, C), float('nan'), device=DEV, dtype=BF), torch.full((M, C), float('nan'), device=DEV, dtype=BF))
+    mean2, rstd2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x, g, b, 1e-6, p, mean2, rstd2)
+    hi, lo = ops.split(y)
+    assert torch.equal(p[0].view(torch.int16), hi.view(torch.int16)) and torch.equal(p[1].view(torch.int16), lo.view(torch.int16))
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
 
 
 @pytest.mark.parametrize('M,N,K', [(306, 64, 64), (306, 192, 128), (4131, 1536, 512), (4131, 512, 1024), (4131, 512, 512), (70227, 512, 512), (33, 64, 64)])
