@@ -236,6 +236,11 @@ int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* l
  * dropped probabilities, dS = P (dP - rowsum(dO o)). */
 int mbx_attn_bwd_drop(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T,
                       int J, int H, int hd, float scale, int mode, int dtype, float p, uint64_t seed, void* stream);
+/* mbx_attn_bwd / mbx_attn_bwd_drop of the fp32 kernels (precision 'bf16x3') with dq | dk | dv written as the two bf16 planes of the
+ * operand split (dqkv_hi, dqkv_lo [M,3C]) instead of fp32: their only readers are the split-operand GEMMs of qkv's backward.  p = 0:
+ * no dropout. */
+int mbx_attn_bwd_planes(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv_hi, void* dqkv_lo, int B, int T,
+                        int J, int H, int hd, float scale, int mode, float p, uint64_t seed, void* stream);
 /* mbx_attn_bwd (bf16) + part[2H][M][2] f32 = per (head, role, token) { sum dqkv rsum, sum dqkv (qkv - bias_f) } of the rounded
  * output over the head's q columns (role 0) and over its k and v columns (role 1) (LayerNorm folding, above; nb = 2H for
  * mbx_lnbwd_rowc; rsum, bias_f f32 [3C], entering rounded to bf16).  part must be 8-byte aligned. */

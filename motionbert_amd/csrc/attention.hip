@@ -203,6 +203,18 @@ __device__ __forceinline__ void store_rowfrag(T* row, const f32x16_t (&acc)[HD /
         }
 }
 
+// the same as the two bf16 planes of the bf16x3 operand split (fp32-class mode: dq / dk / dv are only read by split-operand GEMMs)
+template <int HD>
+__device__ __forceinline__ void store_rowfrag_planes(bf16_t* hi, bf16_t* lo, const f32x16_t (&acc)[HD / 32], int g) {
+#pragma unroll
+    for (int df = 0; df < HD / 32; ++df)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v[4] = {acc[df][4 * q], acc[df][4 * q + 1], acc[df][4 * q + 2], acc[df][4 * q + 3]};
+            store4_planes(hi + df * 32 + 8 * q + 4 * g, lo + df * 32 + 8 * q + 4 * g, v);
+        }
+}
+
 struct Prob {
     size_t tok0;
     size_t dbase;     // flat index of this problem's probability element (0, 0) in the reference's attn tensor (dropout masks)
@@ -349,7 +361,7 @@ template <typename T, int HD, bool SHARED, bool DROP = false>
 __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) == 2 && !DROP) ? 4 : 1) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                           const T* __restrict__ d_o, const float* __restrict__ lse,
                                                           T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
-                                                          int nprob, int KP, MbxDrop dr) {
+                                                          int nprob, int KP, MbxDrop dr, bf16_t* __restrict__ dq_lo) {
     constexpr bool IS_BF = sizeof(T) == 2;
     constexpr int RSTR = rm_stride<T>(HD);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -404,7 +416,11 @@ __global__ __launch_bounds__(AttnBlock<SHARED>::THREADS, (SHARED && sizeof(T) ==
 #pragma unroll
             for (int df = 0; df < HD / 32; ++df) MmaCols<T>::run(kt, RSTR, df * 32, f, s, lane, dq[df]);
         }
-        if (qvalid) store_rowfrag<T, HD>(dqkv + tok * C3 + (size_t)P.h * HD, dq, 1.0f, g);
+        if (qvalid) {
+            const size_t off = tok * C3 + (size_t)P.h * HD;
+            if (sizeof(T) == 4 && dq_lo) store_rowfrag_planes<HD>(reinterpret_cast<bf16_t*>(dqkv) + off, dq_lo + off, dq, g);   // dqkv = the hi plane
+            else store_rowfrag<T, HD>(dqkv + off, dq, 1.0f, g);
+        }
     }
 }
 
@@ -415,7 +431,7 @@ template <typename T, int HD, bool SHARED, bool DROP = false>
 __global__ __launch_bounds__(AttnBlockKV<SHARED>::THREADS, (SHARED && !DROP) ? 2 : 1) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
                                                            const T* __restrict__ d_o, const float* __restrict__ lse,
                                                            T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
-                                                           int nprob, int KP, MbxDrop dr) {
+                                                           int nprob, int KP, MbxDrop dr, bf16_t* __restrict__ dq_lo) {
     constexpr bool IS_BF = sizeof(T) == 2;
     constexpr int RSTR = rm_stride<T>(HD);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -502,8 +518,14 @@ __global__ __launch_bounds__(AttnBlockKV<SHARED>::THREADS, (SHARED && !DROP) ? 2
             }
         }
         if (kvalid) {
-            store_rowfrag<T, HD>(dqkv + tok * C3 + C + (size_t)P.h * HD, dk, 1.0f, g);
-            store_rowfrag<T, HD>(dqkv + tok * C3 + 2 * C + (size_t)P.h * HD, dv, 1.0f, g);
+            const size_t off = tok * C3 + C + (size_t)P.h * HD;
+            if (sizeof(T) == 4 && dq_lo) {
+                store_rowfrag_planes<HD>(reinterpret_cast<bf16_t*>(dqkv) + off, dq_lo + off, dk, g);
+                store_rowfrag_planes<HD>(reinterpret_cast<bf16_t*>(dqkv) + off + C, dq_lo + off + C, dv, g);
+            } else {
+                store_rowfrag<T, HD>(dqkv + off, dk, 1.0f, g);
+                store_rowfrag<T, HD>(dqkv + off + C, dv, 1.0f, g);
+            }
         }
     }
 }
@@ -569,7 +591,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const T* __restrict
                                                              const T* __restrict__ d_o, const float* __restrict__ lse,
                                                              T* __restrict__ dqkv, int Tn, int J, int H, float scale, int mode,
                                                              int nprob, const float* __restrict__ st_bias,
-                                                             const float* __restrict__ st_rsum, float* __restrict__ st_part, MbxDrop dr) {
+                                                             const float* __restrict__ st_rsum, float* __restrict__ st_part, MbxDrop dr,
+                                                             bf16_t* __restrict__ dq_lo) {
     constexpr int KP = 32;
     constexpr int RSTR = rm_stride<T>(HD);
     constexpr int TILE = KP * RSTR;
@@ -755,6 +778,17 @@ constexpr int MBX_ATTN_SMALL_EARLY = 1;
             const uint4 a = *reinterpret_cast<const uint4*>(sa + off);
             const uint4 b = *reinterpret_cast<const uint4*>(sb + off);
             const uint4 c = *reinterpret_cast<const uint4*>(sc + off);
+            if (sizeof(T) == 4 && dq_lo) {      // fp32-class mode: the operand planes of the bf16x3 split (dqkv = the hi plane), four floats per chunk
+                const size_t eo = P.tok0 * C3 + (size_t)P.h * HD + (size_t)r * rstride + ch * 4;
+                bf16_t* const hi = reinterpret_cast<bf16_t*>(dqkv);
+                const float va[4] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+                const float vb[4] = {__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+                const float vc[4] = {__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w)};
+                store4_planes(hi + eo, dq_lo + eo, va);
+                store4_planes(hi + eo + C, dq_lo + eo + C, vb);
+                store4_planes(hi + eo + 2 * C, dq_lo + eo + 2 * C, vc);
+                continue;
+            }
             T* dst = ob + (size_t)r * rstride + ch * (16 / (int)sizeof(T));
             *reinterpret_cast<uint4*>(dst) = a;
             *reinterpret_cast<uint4*>(dst + C) = b;
@@ -1086,7 +1120,7 @@ extern "C" int mbx_attn_fwd_drop(const void* qkv, void* o, float* lse, int B, in
 
 template <typename T, int HD, bool SHARED, bool DROP>
 static int launch_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int Tn, int J, int H,
-                      float scale, int mode, int nprob, int KP, hipStream_t s, const MbxDrop& dr) {
+                      float scale, int mode, int nprob, int KP, hipStream_t s, const MbxDrop& dr, void* dq_lo) {
     constexpr bool IS_BF = sizeof(T) == 2;
     const int RSTR = rm_stride<T>(HD);
     const size_t per_dq = (size_t)2 * KP * RSTR;
@@ -1096,17 +1130,18 @@ static int launch_bwd(const void* qkv, const void* o, const void* d_o, const flo
     auto k2 = attn_bwd_dkv_kernel<T, HD, SHARED, DROP>;
     const size_t shm1 = SHARED ? per_dq : 4 * per_dq, shm2 = SHARED ? per_dkv : 4 * per_dkv;
     if (set_lds(k1, shm1, "attn_bwd_dq") || set_lds(k2, shm2, "attn_bwd_dkv")) return 1;
-    hipLaunchKernelGGL(k1, dim3(grid), dim3(AttnBlock<SHARED>::THREADS), shm1, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP, dr);
+    hipLaunchKernelGGL(k1, dim3(grid), dim3(AttnBlock<SHARED>::THREADS), shm1, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP, dr, (bf16_t*)dq_lo);
     MBX_LAUNCH_CHECK("attn_bwd_dq");
-    hipLaunchKernelGGL(k2, dim3(grid), dim3(AttnBlockKV<SHARED>::THREADS), shm2, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP, dr);
+    hipLaunchKernelGGL(k2, dim3(grid), dim3(AttnBlockKV<SHARED>::THREADS), shm2, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, Tn, J, H, scale, mode, nprob, KP, dr, (bf16_t*)dq_lo);
     MBX_LAUNCH_CHECK("attn_bwd_dkv");
     return 0;
 }
 
 static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
                          int H, int hd, float scale, int mode, int dtype, void* stream, const float* st_bias, const float* st_rsum,
-                         float* st_part, const MbxDrop& dr) {
+                         float* st_part, const MbxDrop& dr, void* dq_lo = nullptr) {
     MBX_CHECK_ARG(qkv && o && d_o && lse && dqkv, "attn_bwd: null pointer");
+    MBX_CHECK_ARG(!dq_lo || dtype == MBX_F32, "attn_bwd: operand planes are an output form of the fp32 kernels");
     MBX_CHECK_ARG(!(st_part && dr.thresh), "attn_bwd: the row dots of the folded LayerNorm backward and dropout do not combine");
     if (check_attn_args("attn_bwd", B, T, J, H, hd, mode, dtype)) return 1;
     const int L = mode == MBX_ATTN_SPATIAL ? J : T;
@@ -1139,7 +1174,7 @@ static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
         auto k = attn_bwd_small_kernel<TT, HDV, DR>;                                                                  \
         if (set_lds(k, shm, "attn_bwd_small")) return 1;                                                              \
         hipLaunchKernelGGL(k, dim3((nprob + 3) / 4), dim3(256), shm, s, (const TT*)qkv, (const TT*)o, (const TT*)d_o, lse, \
-                           (TT*)dqkv, T, J, H, scale, mode, nprob, st_bias, st_rsum, st_part, dr);                    \
+                           (TT*)dqkv, T, J, H, scale, mode, nprob, st_bias, st_rsum, st_part, dr, (bf16_t*)dq_lo);   \
         MBX_LAUNCH_CHECK("attn_bwd_small");                                                                           \
         return 0;                                                                                                     \
     } while (0)
@@ -1151,8 +1186,8 @@ static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
     }
     MBX_CHECK_ARG(!st_part, "attn_bwd_stats: this shape runs the two-kernel backward, which has no row-dot output");
 #define MBX_BWD2(TT, HDV, DR)                                                                                         \
-    (shared ? launch_bwd<TT, HDV, true, DR>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s, dr)           \
-            : launch_bwd<TT, HDV, false, DR>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s, dr))
+    (shared ? launch_bwd<TT, HDV, true, DR>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s, dr, dq_lo)    \
+            : launch_bwd<TT, HDV, false, DR>(qkv, o, d_o, lse, dqkv, T, J, H, scale, mode, nprob, KP, s, dr, dq_lo))
 #define MBX_BWD(TT, HDV) (dr.thresh ? MBX_BWD2(TT, HDV, true) : MBX_BWD2(TT, HDV, false))
     if (dtype == MBX_BF16) return hd == 64 ? MBX_BWD(bf16_t, 64) : MBX_BWD(bf16_t, 32);
     return hd == 64 ? MBX_BWD(float, 64) : MBX_BWD(float, 32);
@@ -1165,6 +1200,14 @@ extern "C" int mbx_attn_bwd(const void* qkv, const void* o, const void* d_o, con
     MbxDrop dr;
     make_drop("attn_bwd", 0.f, 0, dr);
     return attn_bwd_impl(qkv, o, d_o, lse, dqkv, B, T, J, H, hd, scale, mode, dtype, stream, nullptr, nullptr, nullptr, dr);
+}
+// fp32 kernels with dq / dk / dv written as the operand planes of the bf16x3 split (dqkv_hi, dqkv_lo bf16 [M, 3C]); p = 0: no dropout
+extern "C" int mbx_attn_bwd_planes(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv_hi, void* dqkv_lo, int B,
+                                   int T, int J, int H, int hd, float scale, int mode, float p, uint64_t seed, void* stream) {
+    MBX_CHECK_ARG(dqkv_lo, "attn_bwd_planes: null pointer");
+    MbxDrop dr;
+    if (make_drop("attn_bwd_planes", p, seed, dr)) return 1;
+    return attn_bwd_impl(qkv, o, d_o, lse, dqkv_hi, B, T, J, H, hd, scale, mode, MBX_F32, stream, nullptr, nullptr, nullptr, dr, dqkv_lo);
 }
 // backward of mbx_attn_fwd_drop (same p and seed): dP = mask (dO V^T) / (1 - p), dV from the dropped probabilities
 extern "C" int mbx_attn_bwd_drop(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,

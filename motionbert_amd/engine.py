@@ -589,7 +589,7 @@ class Engine:
             dy_t = self._mm(dy)          # bf16x3: the GEMM operand is the split of the fp32 gradient itself
         self._tn(dy_t, self._mm(sv['o']), G[f'{pre}.{attn}.proj.weight'], G[f'{pre}.{attn}.proj.bias'])
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{attn}.proj'], None, EPI_STORE, out_t=do)
-        dqkv = self._t(M, 3 * C)
+        dqkv = self._t(M, 3 * C) if self.fold else self._op(M, 3 * C)     # (bf16x3: the attention backward writes the operand planes itself)
         if self.fold:
             lin = f'{pre}.{attn}.qkv'
             part = self._f(2 * cfg.H, M, 2)       # block-major; per head: the q columns, the k + v columns

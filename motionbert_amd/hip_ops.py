@@ -63,6 +63,7 @@ SIGNATURES = {
     'mbx_gemm_tn_x3_workspace': (_sz, [_i, _i, _i]),
     'mbx_gemm_tn_x3': (_i, [_vp] * 6 + [_i, _i, _i, _vp, _vp]),
     'mbx_attn_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'mbx_attn_bwd_planes': (_i, [_vp] * 6 + [_i, _i, _i, _i, _i, _f, _i, _f, C.c_uint64, _vp]),
     'mbx_attn_bwd': (_i, [_vp] * 5 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'mbx_attn_fwd_drop': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _f, C.c_uint64, _vp]),
     'mbx_attn_bwd_drop': (_i, [_vp] * 5 + [_i, _i, _i, _i, _i, _f, _i, _i, _f, C.c_uint64, _vp]),
@@ -443,6 +444,11 @@ class HipOps:
 
     def attn_bwd(self, qkv, o, do, lse, dqkv, B, T, J, H, scale, mode, drop=None):
         hd = o.shape[-1] // H
+        if isinstance(dqkv, tuple):      # bf16x3 (fp32 kernels): dq / dk / dv as operand planes
+            p, seed = (float(drop[0]), int(drop[1])) if drop is not None and drop[0] > 0 else (0.0, 0)
+            self._ck(self.lib.mbx_attn_bwd_planes(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv[0]), _p(dqkv[1]), B, T, J, H, hd, float(scale),
+                                                  int(mode), p, seed, self._stream()))
+            return
         if drop is not None and drop[0] > 0:
             self._ck(self.lib.mbx_attn_bwd_drop(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, J, H, hd, float(scale), int(mode),
                                                 _DT[qkv.dtype], float(drop[0]), int(drop[1]), self._stream()))

@@ -437,7 +437,13 @@ class MockOps:
             out[:, :, :, 0] = torch.einsum('bjhst,btjhd->bsjhd', ds, k)
             out[:, :, :, 1] = torch.einsum('bjhst,bsjhd->btjhd', ds, q)
             out[:, :, :, 2] = torch.einsum('bjhst,bsjhd->btjhd', pd, do5)
-        dqkv.copy_(out.reshape(dqkv.shape).to(dqkv.dtype))
+        if isinstance(dqkv, tuple):      # bf16x3: dq / dk / dv leave as the operand planes of the GEMMs that read them
+            self._log('planes')
+            hi, lo = self.split(out.reshape(dqkv[0].shape))
+            dqkv[0].copy_(hi)
+            dqkv[1].copy_(lo)
+        else:
+            dqkv.copy_(out.reshape(dqkv.shape).to(dqkv.dtype))
 
     # fusion ----------------------------------------------------------------
     def fuse_fwd(self, x_st, x_ts, w, b, out, alpha):

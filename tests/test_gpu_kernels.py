@@ -376,6 +376,12 @@ def test_attention(ops, dt, mode, B, T, H, hd):
     floor = float(dq2[:, 2 * C:].float().norm()) if (T if mode == MODE_TEMPORAL else J) == 1 else 0.0
     for i, n in enumerate(['dq', 'dk', 'dv']):
         check(f'attn_bwd.{n}.{tag}', dq[:, i * C:(i + 1) * C], dq2[:, i * C:(i + 1) * C], 5e-5 if dt == torch.float32 else 2e-2, floor)
+    if dt == torch.float32:      # the same gradients as the operand planes of the bf16x3 split: bit for bit the split of the fp32 output
+        BF = torch.bfloat16
+        pl = (torch.full((M, 3 * C), 9.0, device=DEV, dtype=BF), torch.full((M, 3 * C), 9.0, device=DEV, dtype=BF))
+        ops.attn_bwd(qkv, o2, do, lse2, pl, B, T, J, H, scale, mode)
+        hi, lo = ops.split(dq)
+        assert torch.equal(pl[0].view(torch.int16), hi.view(torch.int16)) and torch.equal(pl[1].view(torch.int16), lo.view(torch.int16)), tag
 
 
 @pytest.mark.parametrize('dt', TD)
