@@ -81,6 +81,11 @@ size_t mbx_layernorm_bwd_ws(int C);
 int mbx_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dres, const float* extra, float* dx, void* dx_t, float* dgamma, float* dbeta,
                       int M, int C, int dtype, void* ws, void* stream);
+/* mbx_layernorm_bwd (T = f32) with the T copy of dx written as operand planes (dx_hi, dx_lo bf16 [M,C]): in the fp32-class mode the next
+ * sub-layer's backward reads the gradient of the residual stream as fp32 (dx) and as a split-operand GEMM operand. */
+int mbx_layernorm_bwd_planes(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                             const float* extra, float* dx, void* dx_hi, void* dx_lo, float* dgamma, float* dbeta, int M, int C,
+                             void* ws, void* stream);
 
 /* ---- GEMMs on MFMA -------------------------------------------------------------------------
  * acc[M,N] = a[M,K] . w[N,K]^T  (nn.Linear, DSTformer.py:74,76,97,103,295), epilogue per mbx_epilogue.

@@ -615,7 +615,7 @@ template <typename T, int VPL, bool FULL, bool RES>
 __device__ __forceinline__ void ln_bwd_row(const typename Raw4<T>::type (&rd)[VPL], const float4 (&rx)[VPL], const float4 (&rr)[VPL],
                                            float mu, float rs, const float (&g)[VPL][4], float (&ag)[VPL][4], float (&ab)[VPL][4],
                                            float invC, const float* __restrict__ extra, float* __restrict__ dx, T* __restrict__ dx_t,
-                                           int row, int C, int lane) {
+                                           int row, int C, int lane, bf16_t* __restrict__ dx_lo = nullptr) {
     float d[VPL][4], xh[VPL][4];
     float s1 = 0.f, s2 = 0.f;
     ROW_LOOP(k) {
@@ -655,7 +655,9 @@ __device__ __forceinline__ void ln_bwd_row(const typename Raw4<T>::type (&rd)[VP
                 for (int i = 0; i < 4; ++i) r[i] += t[i];
             }
             store4<float>(dx + (size_t)row * C + c, r);
-            if (dx_t) store4<T>(dx_t + (size_t)row * C + c, r);
+            if (sizeof(T) == 4 && dx_lo)      // fp32-class mode: dx_t = the operand planes of the next sub-layer's split-operand GEMMs
+                store4_planes(reinterpret_cast<bf16_t*>(dx_t) + (size_t)row * C + c, dx_lo + (size_t)row * C + c, r);
+            else if (dx_t) store4<T>(dx_t + (size_t)row * C + c, r);
         }
     }
 }
@@ -664,7 +666,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      const float* __restrict__ extra, float* __restrict__ dx,
-                                                     T* __restrict__ dx_t, float* __restrict__ part, int M, int C) {
+                                                     T* __restrict__ dx_t, float* __restrict__ part, int M, int C,
+                                                     bf16_t* __restrict__ dx_lo) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float g[VPL][4], ag[VPL][4], ab[VPL][4];
@@ -683,8 +686,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         float mua, rsa, mub, rsb;
         ln_bwd_load<T, VPL, FULL, RES>(dy, x, dres, mean, rstd, row0, C, lane, da, xa, ra, mua, rsa);
         if (row1 < M) ln_bwd_load<T, VPL, FULL, RES>(dy, x, dres, mean, rstd, row1, C, lane, db, xb, rb, mub, rsb);
-        ln_bwd_row<T, VPL, FULL, RES>(da, xa, ra, mua, rsa, g, ag, ab, invC, extra, dx, dx_t, row0, C, lane);
-        if (row1 < M) ln_bwd_row<T, VPL, FULL, RES>(db, xb, rb, mub, rsb, g, ag, ab, invC, extra, dx, dx_t, row1, C, lane);
+        ln_bwd_row<T, VPL, FULL, RES>(da, xa, ra, mua, rsa, g, ag, ab, invC, extra, dx, dx_t, row0, C, lane, dx_lo);
+        if (row1 < M) ln_bwd_row<T, VPL, FULL, RES>(db, xb, rb, mub, rsb, g, ag, ab, invC, extra, dx, dx_t, row1, C, lane, dx_lo);
     }
     float* mine = lds + (size_t)wave * 2 * C;
     ROW_LOOP(k) {
@@ -696,16 +699,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 }
 #define LN_BWD_LAUNCH(TT, FULLV, RESV)                                                                                        \
     DISPATCH_VPL(vpl, hipLaunchKernelGGL((ln_bwd_kernel<TT, VPL, FULLV, RESV>), dim3(grid), dim3(256), shm, s, (const TT*)dy, x, mean, \
-                                         rstd, gamma, dres, extra, dx, (TT*)dx_t, part, M, C))
+                                         rstd, gamma, dres, extra, dx, (TT*)dx_t, part, M, C, (bf16_t*)dx_lo))
 #define LN_BWD_LAUNCH_T(TT)                                                            \
     if (full && dres) { LN_BWD_LAUNCH(TT, true, true); }                               \
     else if (full) { LN_BWD_LAUNCH(TT, true, false); }                                 \
     else if (dres) { LN_BWD_LAUNCH(TT, false, true); }                                 \
     else { LN_BWD_LAUNCH(TT, false, false); }
 extern "C" size_t mbx_layernorm_bwd_ws(int C) { return (size_t)LN_BLOCKS * 2 * C * sizeof(float); }
+static int launch_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* dres, const float* extra, float* dx, void* dx_t, void* dx_lo, float* dgamma, float* dbeta,
+                                int M, int C, int dtype, void* ws, void* stream);
 extern "C" int mbx_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* dres, const float* extra, float* dx, void* dx_t, float* dgamma, float* dbeta,
                                  int M, int C, int dtype, void* ws, void* stream) {
+    return launch_layernorm_bwd(dy, x, mean, rstd, gamma, dres, extra, dx, dx_t, nullptr, dgamma, dbeta, M, C, dtype, ws, stream);
+}
+extern "C" int mbx_layernorm_bwd_planes(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                        const float* dres, const float* extra, float* dx, void* dx_hi, void* dx_lo, float* dgamma,
+                                        float* dbeta, int M, int C, void* ws, void* stream) {
+    MBX_CHECK_ARG(dx_hi && dx_lo, "layernorm_bwd_planes: null pointer");
+    return launch_layernorm_bwd(dy, x, mean, rstd, gamma, dres, extra, dx, dx_hi, dx_lo, dgamma, dbeta, M, C, MBX_F32, ws, stream);
+}
+static int launch_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* dres, const float* extra, float* dx, void* dx_t, void* dx_lo, float* dgamma, float* dbeta,
+                                int M, int C, int dtype, void* ws, void* stream) {
     MBX_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
     MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "layernorm_bwd: bad shape M=%d C=%d", M, C);
     MBX_CHECK_ARG(dtype == MBX_BF16 || dtype == MBX_F32, "layernorm_bwd: unknown dtype %d", dtype);

@@ -439,11 +439,14 @@ class Engine:
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode, drop=(dm[5], dm[6]))
         else:
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
-        y, ln_y = self._resid_gemm(self._mm(o), f'{pre}.{attn}.proj', x, dm, pre, nxt)
+        o_op = self._mm(o)      # (bf16x3: the operand planes are kept for the weight gradient too -- o itself stays fp32 for the attention backward)
+        y, ln_y = self._resid_gemm(o_op, f'{pre}.{attn}.proj', x, dm, pre, nxt)
         if self.fold:      # backward needs xhat and rstd only: the fp32 sub-layer input is not kept
             sv = dict(x=None, mean=None, rstd=rstd, xn=xn, qkv=qkv, o=o, lse=lse, dm=dm) if need_grad else None
         else:
             sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, qkv=qkv, o=o, lse=lse, dm=dm) if need_grad else None
+        if sv is not None and self.x3 and self.x3_planes and not self.recompute:
+            sv['o_op'] = o_op
         return y, sv, ln_y
 
     def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1, ln=None, nxt=None):
@@ -585,9 +588,9 @@ class Engine:
             ops.grad_drop(dy, dy_t, cfg.J, dm[0], dm[1], dm[3], dm[4])
             if self.x3:
                 dy_t = self._mm(dy_t)
-        elif self.x3:
-            dy_t = self._mm(dy)          # bf16x3: the GEMM operand is the split of the fp32 gradient itself
-        self._tn(dy_t, self._mm(sv['o']), G[f'{pre}.{attn}.proj.weight'], G[f'{pre}.{attn}.proj.bias'])
+        elif self.x3 and not isinstance(dy_t, tuple):
+            dy_t = self._mm(dy)          # bf16x3: the GEMM operand is the split of the fp32 gradient itself (unless its producer wrote the planes)
+        self._tn(dy_t, sv['o_op'] if 'o_op' in sv else self._mm(sv['o']), G[f'{pre}.{attn}.proj.weight'], G[f'{pre}.{attn}.proj.bias'])
         ops.gemm_nt(dy_t, self.Wt[f'{pre}.{attn}.proj'], None, EPI_STORE, out_t=do)
         dqkv = self._t(M, 3 * C) if self.fold else self._op(M, 3 * C)     # (bf16x3: the attention backward writes the operand planes itself)
         if self.fold:
@@ -608,7 +611,7 @@ class Engine:
         ops.gemm_nt(dqkv, self.Wt[f'{pre}.{attn}.qkv'], None, EPI_STORE, out_t=dxn)
         del dqkv
         dx = self._f(M, C)
-        dx_t = self._t(M, C) if need_t and not self.x3 else None
+        dx_t = (self._t(M, C) if not self.x3 else (self._op(M, C) if self.x3_planes else None)) if need_t else None      # bf16x3: operand planes
         if callable(extra):      # dual-stream backward: the other block's input gradient, awaited only now
             extra = extra()
         ops.layernorm_bwd(dxn, sv['x'], sv['mean'], sv['rstd'], P[f'{pre}.{norm}.weight'], dy, extra,
@@ -664,7 +667,7 @@ class Engine:
             ops.grad_drop(dy, dy_t, cfg.J, dm[0], dm[1], dm[3], dm[4])
             if self.x3:
                 dy_t = self._mm(dy_t)
-        elif self.x3:
+        elif self.x3 and not isinstance(dy_t, tuple):
             dy_t = self._mm(dy)
         g = sv['g']
         if g is None:                                         # recompute mode: post-activation from the saved pre-activation
@@ -691,7 +694,7 @@ class Engine:
         ops.gemm_nt(du, self.Wt[f'{pre}.{mlp}.fc1'], None, EPI_STORE, out_t=dxn)
         del du
         dx = self._f(M, C)
-        dx_t = self._t(M, C) if need_t and not self.x3 else None
+        dx_t = (self._t(M, C) if not self.x3 else (self._op(M, C) if self.x3_planes else None)) if need_t else None      # bf16x3: operand planes
         if callable(extra):      # dual-stream backward: the other block's input gradient, awaited only now
             extra = extra()
         ops.layernorm_bwd(dxn, sv['x'], sv['mean'], sv['rstd'], P[f'{pre}.{norm}.weight'], dy, extra,

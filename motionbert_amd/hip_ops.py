@@ -58,6 +58,7 @@ SIGNATURES = {
     'mbx_gelu_fwd': (_i, [_vp, _vp, _sz, _i, _vp]),
     'mbx_split_bf16': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'mbx_gemm_nt_x3p': (_i, [_vp] * 5 + [_i] + [_vp] * 4 + [_i, _i, _i, _vp]),
+    'mbx_layernorm_bwd_planes': (_i, [_vp] * 12 + [_i, _i, _vp, _vp]),
     'mbx_layernorm_fwd_planes': (_i, [_vp] * 3 + [_f] + [_vp] * 4 + [_i, _i, _vp]),
     'mbx_gemm_nt_x3': (_i, [_vp] * 5 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),
     'mbx_gemm_tn_x3_workspace': (_sz, [_i, _i, _i]),
@@ -383,6 +384,10 @@ class HipOps:
     def layernorm_bwd(self, dy_t, x, mean, rstd, g, dres, extra, dx, dx_t, dg, db):
         M, Cc = x.shape
         ws = self._ws(('lnb', Cc), self.lib.mbx_layernorm_bwd_ws, Cc, device=x.device)
+        if isinstance(dx_t, tuple):      # bf16x3: the T copy of dx as operand planes
+            self._ck(self.lib.mbx_layernorm_bwd_planes(_p(dy_t), _p(x), _p(mean), _p(rstd), _p(g), _p(dres), _p(extra), _p(dx), _p(dx_t[0]),
+                                                       _p(dx_t[1]), _p(dg), _p(db), M, Cc, _p(ws), self._stream()))
+            return
         self._ck(self.lib.mbx_layernorm_bwd(_p(dy_t), _p(x), _p(mean), _p(rstd), _p(g), _p(dres), _p(extra), _p(dx), _p(dx_t),
                                             _p(dg), _p(db), M, Cc, _DT[dy_t.dtype], _p(ws), self._stream()))
 

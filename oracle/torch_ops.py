@@ -173,7 +173,12 @@ class MockOps:
         if extra is not None:
             r = r + extra
         dx.copy_(r)
-        if dx_t is not None:
+        if isinstance(dx_t, tuple):      # bf16x3: the T copy as operand planes
+            self._log('planes')
+            hi, lo = self.split(r)
+            dx_t[0].copy_(hi)
+            dx_t[1].copy_(lo)
+        elif dx_t is not None:
             dx_t.copy_(r.to(dx_t.dtype))
 
     # GEMMs ----------------------------------------------------------------

@@ -332,6 +332,16 @@ def test_layernorm_fwd_planes(ops, M, C, affine):
     hi, lo = ops.split(y)
     assert torch.equal(p[0].view(torch.int16), hi.view(torch.int16)) and torch.equal(p[1].view(torch.int16), lo.view(torch.int16))
     assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    if affine:      # backward: the T copy of dx as operand planes = the split of dx, bit for bit; everything else unchanged
+        dy, dres = rnd(M, C, seed=4), rnd(M, C, seed=5)
+        dx, dg, db = torch.empty(M, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        dx2, dg2, db2 = torch.empty(M, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        ops.layernorm_bwd(dy, x, mean, rstd, g, dres, None, dx, None, dg, db)
+        q = (torch.full((M, C), float('nan'), device=DEV, dtype=BF), torch.full((M, C), float('nan'), device=DEV, dtype=BF))
+        ops.layernorm_bwd(dy, x, mean, rstd, g, dres, None, dx2, q, dg2, db2)
+        hi, lo = ops.split(dx)
+        assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+        assert torch.equal(q[0].view(torch.int16), hi.view(torch.int16)) and torch.equal(q[1].view(torch.int16), lo.view(torch.int16))
 
 
 @pytest.mark.parametrize('M,N,K', [(306, 64, 64), (306, 192, 128), (4131, 1536, 512), (4131, 512, 1024), (4131, 512, 512), (70227, 512, 512), (33, 64, 64)])
