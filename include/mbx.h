@@ -179,6 +179,15 @@ int mbx_mlp_pack_weights(const void* w1, const void* w2, void* packed, int C, in
 int mbx_mlp_fused_fwd(const void* a, int raw_in, const void* packed, const float* b1, const float* b2, const float* rsum,
                       const float* resid, float* y, void* y_t, float eps, float* mean, float* rstd, int M, int C, int hidden,
                       void* stream);
+/* The attention's proj + residual in front of the MLP, same kernel (DSTformer.py:241-249: x + attn(..) then x + mlp(norm(..)); :103 proj):
+ *     y1 = resid + o . Wp^T + bp        y = y1 + fc2(gelu_erf(fc1(LN(y1))))
+ * o bf16 [M,C] = the attention output (mbx_attn_fwd); y1 exists only in the accumulator registers: its bf16 rounding is fc1's operand,
+ * its LayerNorm statistics are taken from the same registers.  packed: mbx_proj_mlp_pack_weights(wp bf16 [C,C], w1 (folded), w2) ->
+ * mbx_proj_mlp_pack_bytes(C, hidden) bytes;  bp [C], b1 [hidden] (folded), b2 [C], rsum [hidden];  y may alias resid. */
+size_t mbx_proj_mlp_pack_bytes(int C, int hidden);
+int mbx_proj_mlp_pack_weights(const void* wp, const void* w1, const void* w2, void* packed, int C, int hidden, void* stream);
+int mbx_proj_mlp_fused_fwd(const void* o, const void* packed, const float* bp, const float* b1, const float* b2, const float* rsum,
+                           const float* resid, float* y, float eps, int M, int C, int hidden, void* stream);
 
 /* ---- "row owner" NT GEMMs (bf16; csrc/gemm_rows.hip) -----------------------------------------------
  * The same Linear layers (DSTformer.py:97 qkv, :69 fc1; the input gradients of :70 fc2 and :103 proj) on a kernel whose workgroup

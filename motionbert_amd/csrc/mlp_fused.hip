@@ -81,6 +81,17 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const bf16_t* __restrict_
     *reinterpret_cast<uint4*>(out + (size_t)frag * 512 + lane * 8) = v;
 }
 
+// proj part of the stream (the kernel's PROJ form: attention proj + residual in front of the MLP): fragment (kk, nt) at index
+// kk C/32 + nt, lane (i, g): Wp[32 nt + i][16 kk + 8 g + t] -- the fc1 fragment format, k-step-major so that one token fragment
+// serves the C/32 output tiles of a k-step in a row.
+__global__ __launch_bounds__(256) void mlp_pack_proj_kernel(const bf16_t* __restrict__ wp, bf16_t* __restrict__ out, int C) {
+    const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nt2 = C / 32;
+    if (frag >= (C / 16) * nt2) return;
+    const int kk = frag / nt2, nt = frag % nt2, i = lane & 31, g = lane >> 5;
+    *reinterpret_cast<uint4*>(out + (size_t)frag * 512 + lane * 8) = *reinterpret_cast<const uint4*>(wp + (size_t)(32 * nt + i) * C + 16 * kk + 8 * g);
+}
+
 // XOR applied to the 16-byte piece index of the X image so that the fragment reads (32 rows, one piece each) are conflict-free
 // for ds_read_b128's 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}: rows r = i & 7 of row group rb = i >> 3
 __device__ __forceinline__ int x_swz(int r, int rb) { return ((r >> 1) & 3) | (((rb >> 1) & 1) << 2); }
@@ -92,12 +103,19 @@ __device__ __forceinline__ float2 ge_bias_ld(const char* p) {
     return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
 }
 
-template <int C>
+// PROJ (round 4, last step of the no-grad path): the attention's proj + residual runs in front of the MLP in the same kernel --
+//     y1 = resid + xh . Wp^T + bp   (xh = the attention output o, bf16)      y = y1 + fc2(gelu(fc1(LayerNorm(y1))))
+// The fc2 accumulators (which start from resid + bp) take the proj product first, C/16 k-steps x C/32 tiles with the token
+// fragments of o where X will live; then every lane turns its accumulator registers into the fc1 operand bf16(y1) in registers
+// (the accumulator layout holds columns 8 q + 4 g + e of a token, an operand fragment 8 consecutive ones: one v_permlane32_swap
+// per register pair) and takes the LayerNorm statistics of y1 from the same values.  y1 never exists in HBM (- 8 bytes per element),
+// one launch less per Block half.
+template <int C, bool PROJ = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restrict__ xh, const char* __restrict__ wpk,
                                                            const float* __restrict__ b1, const float* __restrict__ b2,
                                                            const float* __restrict__ rsum, int raw_in, const float* resid, float* y,
                                                            bf16_t* __restrict__ yb_out, float eps, float* __restrict__ mean_out,
-                                                           float* __restrict__ rstd_out, int M, int hidden) {
+                                                           float* __restrict__ rstd_out, int M, int hidden, const float* __restrict__ bp) {
     constexpr int NT2 = C / 32;            // 32-column tiles of the output row
     constexpr int KS = C / 16;             // fc1 k-steps
     constexpr int S2 = C / 256;            // stages per fc1 part and per fc2 part of a chunk
@@ -120,14 +138,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     float* const rss = b1s + hidden;
     float* const b2s = rss + hidden;
     char* const xsp = reinterpret_cast<char*>(b2s + C) + wave * (XL * 1024) + lane * 16;
+    constexpr int NPS = PROJ ? KS * NT2 / 32 : 0;   // stages of the proj part of the stream
     const int nch = hidden / F_CH, NS = nch * 2 * S2;
+    float* const bps = reinterpret_cast<float*>(smem + F_RING + (size_t)(2 * hidden + C) * 4 + (C == 512 ? 4 * 4096 : 0));   // PROJ: bp [C] behind everything else
 
     // (Measured and dropped, round 4: a start stagger of the first workgroup of every CU by k/8 of a tile period, to run the memory
     // phases of some CUs under the compute phases of the others -- 101.2 us per tile round with and 102.7-103.3 without, i.e. null:
     // the CUs are not phase-locked.  Prologue-only and epilogue-only builds run at 4.8 / 5.4 TB/s = ~11 B/clk per CU, the per-CU
     // miss-bandwidth limit, and that time ADDS to the loop's: profiles/r04_mlp_fused_ablation.txt.)
     for (int k = tid; k < hidden; k += 256) { b1s[k] = b1[k]; rss[k] = raw_in ? rsum[k] : 0.f; }
-    for (int k = tid; k < C; k += 256) b2s[k] = b2[k];
+    for (int k = tid; k < C; k += 256) { b2s[k] = b2[k]; if (PROJ) bps[k] = bp[k] + b2[k]; }
 
     // ---- X, the token operand of fc1, and the row constants of the raw-operand LayerNorm: fc1 = rstd acc + (b' - rstd mean rsum).
     //   xh given, raw_in = 0: xh is the normalised operand; constants (1, 0): fc1 = 1 acc + (b' + 0 rsum).
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             const int rb = i >> 3, r = i & 7, p = 2 * (s & 3) + g;
             X[s] = *reinterpret_cast<const u32x4_t*>(ximg + ((s >> 2) * 4 + rb) * 1024 + r * 128 + ((p ^ x_swz(r, rb)) << 4));
         }
-        if (raw_in) {                              // wave-uniform
+        if (raw_in && !PROJ) {                     // wave-uniform (PROJ: the operand of fc1 and its statistics come from the proj product)
             float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             f32x16_t t;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const float4 bb = *reinterpret_cast<const float4*>(b2s + nt * 32 + 8 * qq + 4 * g);
+                const float4 bb = *reinterpret_cast<const float4*>((PROJ ? bps : b2s) + nt * 32 + 8 * qq + 4 * g);   // (PROJ: bp + b2)
                 const float4 xv = *reinterpret_cast<const float4*>(er + i * 1024 + (((ntl * 8 + 2 * qq + g) ^ (i & 15)) << 4));
                 t[4 * qq] = xv.x + bb.x; t[4 * qq + 1] = xv.y + bb.y; t[4 * qq + 2] = xv.z + bb.z; t[4 * qq + 3] = xv.w + bb.w;
                 if (from_x) {
@@ -225,19 +245,23 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         ln_rs = 1.0f / sqrtf(var + eps);
         ln_k = -ln_rs * 0.5f * (mean_h + mean_o);
     }
+    if constexpr (!PROJ) {                         // (PROJ: X is made after the proj product, below)
 #pragma unroll
-    for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
+        for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // every wave is done with its image: the ring is free
 
     // ---- weight stream -------------------------------------------------------------------------------------------------------
     // stage sequence q -> byte offset in the packed stream:  A(0) | A(1) B(0) | A(2) B(1) | ... | A(n-1) B(n-2) | B(n-1)
     // (past the end: a harmless re-read of the last stage into a slot nobody reads again, so that the wait counts stay constant)
+    // (PROJ: the NPS stages of the proj product come first, in order)
     auto seq_off = [&](int qq) -> int {
-        const int qc = min(qq, NS - 1), k = qc - S2, grp = k / (2 * S2), r = k % (2 * S2);
+        if (PROJ && qq < NPS) return qq * F_STAGE;
+        const int qc = min(qq - NPS, NS - 1), k = qc - S2, grp = k / (2 * S2), r = k % (2 * S2);
         const int mid = (r < S2 ? grp + 1 : grp) * CHB + r * F_STAGE;
         const int last = (nch - 1) * CHB + (S2 + r) * F_STAGE;
-        return qc < S2 ? qc * F_STAGE : (grp >= nch - 1 ? last : mid);
+        return NPS * F_STAGE + (qc < S2 ? qc * F_STAGE : (grp >= nch - 1 ? last : mid));
     };
     // piece d of a stage = its fragments 4 d .. 4 d + 3, one per wave: this lane's 16 bytes sit at stage + 4096 d + 1024 wave + 16 lane
     const unsigned wvo = wave * 1024 + lane * 16;
@@ -385,6 +409,65 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         if constexpr (S2 == 2) MF_STAGE(MMA_A1, HOOK_PA1);                                                           \
     } while (0)
 
+    if constexpr (PROJ) {
+        // ---- proj: acc2 (= resid + bp) += o . Wp^T.  One stage = 32 / NT2 k-steps x NT2 output tiles; the token fragments of the
+        // stage's k-steps are copied out of X into fixed registers first (X cannot be indexed by the stage counter).
+        u32x4_t xk[KKS];
+#define MMA_P(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, xk[(k_) / NT2])
+        for (int p = 0; p < NPS; ++p) {
+#pragma unroll
+            for (int pp = 0; pp < NPS; ++pp)
+                if (p == pp) {
+#pragma unroll
+                    for (int j = 0; j < KKS; ++j) xk[j] = X[KKS * pp + j];
+                }
+            MF_STAGE(MMA_P, HOOK_NONE);
+        }
+        // ---- y1 sits in the accumulators: operand fragments and LayerNorm statistics from them.  Lane (i, g) holds columns
+        // 32 nt + 8 q + 4 g + e of token i in acc2[nt][4 q + e]; fragment s = 2 nt + h wants its columns 16 s + 8 g + [0, 8): quads
+        // q = 2 h + g of BOTH half waves.  v_permlane32_swap(a, b) exchanges a's upper half with b's lower half: from
+        // (a, b) = registers e of quads (2 h, 2 h + 1) every lane gets its own quad's value of lane (i, 0) in a and of lane (i, 1) in b.
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) MFMA_PAD_A(acc2[t]);
+        float sh = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            f32x16_t t = acc2[nt];                                 // y1 + b2 (the accumulators started from resid + bp + b2, so that the
+#pragma unroll                                                     // epilogue stays a pure read of them): take b2 off again
+            for (int qq = 0; qq < 4; ++qq) {
+                const float4 bb = *reinterpret_cast<const float4*>(b2s + nt * 32 + 8 * qq + 4 * g);
+                t[4 * qq] -= bb.x; t[4 * qq + 1] -= bb.y; t[4 * qq + 2] -= bb.z; t[4 * qq + 3] -= bb.w;
+            }
+            if (nt == 0) sh = t[0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = t[r] - sh; s1 += d; s2 = fmaf(d, d, s2); }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float a[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = t[8 * h + e];
+                    b[e] = t[8 * h + 4 + e];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[e]), "+v"(b[e]));
+                }
+                X[2 * nt + h] = u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+                asm volatile("" : "+v"(X[2 * nt + h]));      // packed HERE (otherwise the conversions sink to the fragment's first use and the floats spill)
+            }
+            __builtin_amdgcn_sched_barrier(0);                    // one tile's 16 registers at a time out of the accumulator file
+        }
+        {
+            constexpr float nh = (float)(C / 2);
+            const float mean_h = sh + s1 / nh, m2_h = s2 - s1 * s1 / nh;
+            const float mean_o = wave_halves<WaveAdd>(mean_h) - mean_h;
+            const float m2_both = wave_halves<WaveAdd>(m2_h);
+            const float delta = mean_o - mean_h;
+            const float var = fmaxf((m2_both + delta * delta * (nh * 0.5f)) / (float)C, 0.f);
+            ln_rs = 1.0f / sqrtf(var + eps);
+            ln_k = -ln_rs * 0.5f * (mean_h + mean_o);
+        }
+#pragma unroll
+        for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
+    }
     // A(0), gelu(0): the only GELU that overlaps nothing
     MF_PART_A();
     MFMA_PAD_V(acc1[0], acc1[1]);
@@ -482,14 +565,15 @@ extern "C" int mbx_mlp_pack_weights(const void* w1, const void* w2, void* packed
     return 0;
 }
 
-template <int C>
+template <int C, bool PROJ>
 static int launch_mlp_fused(const void* a, const void* packed, const float* b1, const float* b2, const float* rsum, int raw_in,
-                            const float* resid, float* y, void* yb, float eps, float* mean, float* rstd, int M, int hidden, hipStream_t s) {
-    const size_t shm = F_RING + (size_t)(2 * hidden + C) * sizeof(float) + (C == 512 ? 4 * 4096 : 0);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                            const float* resid, float* y, void* yb, float eps, float* mean, float* rstd, int M, int hidden, hipStream_t s,
+                            const float* bp = nullptr) {
+    const size_t shm = F_RING + (size_t)(2 * hidden + C) * sizeof(float) + (C == 512 ? 4 * 4096 : 0) + (PROJ ? C * sizeof(float) : 0);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<C, PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return mbx_set_error("mlp_fused_fwd: cannot reserve %zu bytes of LDS", shm);
-    hipLaunchKernelGGL(mlp_fused_kernel<C>, dim3((M + F_BM - 1) / F_BM), dim3(256), shm, s, (const bf16_t*)a, (const char*)packed, b1, b2,
-                       rsum, raw_in, resid, y, (bf16_t*)yb, eps, mean, rstd, M, hidden);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, PROJ>), dim3((M + F_BM - 1) / F_BM), dim3(256), shm, s, (const bf16_t*)a, (const char*)packed, b1, b2,
+                       rsum, raw_in, resid, y, (bf16_t*)yb, eps, mean, rstd, M, hidden, bp);
     MBX_LAUNCH_CHECK("mlp_fused_fwd");
     return 0;
 }
@@ -504,6 +588,28 @@ extern "C" int mbx_mlp_fused_fwd(const void* a, int raw_in, const void* packed, 
     MBX_CHECK_ARG(!raw_in || rsum, "mlp_fused_fwd: a raw operand needs rsum (row sums of the folded fc1 weights)");
     MBX_CHECK_ARG((mean && rstd) || (!mean && !rstd), "mlp_fused_fwd: mean and rstd come together");
     hipStream_t s = (hipStream_t)stream;
-    if (C == 512) return launch_mlp_fused<512>(a, packed, b1, b2, rsum, raw_in, resid, y, y_t, eps, mean, rstd, M, hidden, s);
-    return launch_mlp_fused<256>(a, packed, b1, b2, rsum, raw_in, resid, y, y_t, eps, mean, rstd, M, hidden, s);
+    if (C == 512) return launch_mlp_fused<512, false>(a, packed, b1, b2, rsum, raw_in, resid, y, y_t, eps, mean, rstd, M, hidden, s);
+    return launch_mlp_fused<256, false>(a, packed, b1, b2, rsum, raw_in, resid, y, y_t, eps, mean, rstd, M, hidden, s);
+}
+
+// ---- attention proj + residual + the MLP sub-layer in one kernel (the PROJ form above) --------------------------------------------
+extern "C" size_t mbx_proj_mlp_pack_bytes(int C, int hidden) { return (size_t)C * C * sizeof(bf16_t) + mbx_mlp_pack_bytes(C, hidden); }
+
+extern "C" int mbx_proj_mlp_pack_weights(const void* wp, const void* w1, const void* w2, void* packed, int C, int hidden, void* stream) {
+    MBX_CHECK_ARG(wp && w1 && w2 && packed, "proj_mlp_pack_weights: null pointer");
+    MBX_CHECK_ARG((C == 256 || C == 512) && hidden > 0 && hidden % F_CH == 0, "proj_mlp_pack_weights: C=%d (256 or 512), hidden=%d (%% 64)", C, hidden);
+    const int nfp = (C / 16) * (C / 32);
+    hipLaunchKernelGGL(mlp_pack_proj_kernel, dim3((nfp + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)wp, (bf16_t*)packed, C);
+    MBX_LAUNCH_CHECK("proj_mlp_pack_weights");
+    return mbx_mlp_pack_weights(w1, w2, (char*)packed + (size_t)C * C * sizeof(bf16_t), C, hidden, stream);
+}
+
+extern "C" int mbx_proj_mlp_fused_fwd(const void* o, const void* packed, const float* bp, const float* b1, const float* b2,
+                                      const float* rsum, const float* resid, float* y, float eps, int M, int C, int hidden, void* stream) {
+    MBX_CHECK_ARG(o && packed && bp && b1 && b2 && rsum && resid && y, "proj_mlp_fused_fwd: null pointer");
+    MBX_CHECK_ARG(M > 0 && (C == 256 || C == 512) && hidden >= F_CH && hidden % F_CH == 0 && hidden <= 1536,
+                  "proj_mlp_fused_fwd: bad shape M=%d C=%d (256 or 512) hidden=%d (%% 64, 64..1536)", M, C, hidden);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 512) return launch_mlp_fused<512, true>(o, packed, b1, b2, rsum, 1, resid, y, nullptr, eps, nullptr, nullptr, M, hidden, s, bp);
+    return launch_mlp_fused<256, true>(o, packed, b1, b2, rsum, 1, resid, y, nullptr, eps, nullptr, nullptr, M, hidden, s, bp);
 }

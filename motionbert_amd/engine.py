@@ -169,7 +169,8 @@ class Engine:
         # no-grad sequencing of a Block (decided per forward): raw-operand LayerNorm + fused MLP, see the module docstring
         self.rawln = False
         self.rawln_allowed = os.environ.get('MBX_RAWLN', '1') == '1'      # A/B switch: 0 = the training sequencing without saves
-        self.Pk: Dict[str, torch.Tensor] = {}       # fc1 / fc2 of every MLP in the fragment order of mbx_mlp_fused_fwd
+        self.Pk: Dict[str, torch.Tensor] = {}       # fc1 / fc2 of every MLP (with the proj in front of it) in the fragment order of the fused kernels
+        self.proj_mlp = os.environ.get('MBX_PROJ_MLP', '1') == '1' and hasattr(ops, 'proj_mlp_fused_fwd')      # A/B switch: 0 = proj + residual as its own GEMM
         # residual GEMM + the next LayerNorm forward in one launch (round 3, bf16 path; include/mbx.h): decided at the first forward
         # (the provider checks the device's workgroup -> XCD rule once).  Opt-in with MBX_RESID_LN=1: measured time-neutral at 64 clips
         self.resid_ln = None
@@ -269,9 +270,12 @@ class Engine:
             if self.rawln:
                 for stream in ('blocks_st', 'blocks_ts'):
                     for i in range(cfg.depth):
-                        for m in ('mlp_s', 'mlp_t'):
+                        for m, a in (('mlp_s', 'attn_s'), ('mlp_t', 'attn_t')):      # every MLP follows the attention of its own kind
                             pre = f'{stream}.{i}.{m}'
-                            self.Pk[pre] = ops.mlp_pack_weights(self.Wn[pre + '.fc1'], self.Wn[pre + '.fc2'])
+                            if self.proj_mlp:
+                                self.Pk[pre] = ops.proj_mlp_pack_weights(self.Wn[f'{stream}.{i}.{a}.proj'], self.Wn[pre + '.fc1'], self.Wn[pre + '.fc2'])
+                            else:
+                                self.Pk[pre] = ops.mlp_pack_weights(self.Wn[pre + '.fc1'], self.Wn[pre + '.fc2'])
                         for a in ('attn_s', 'attn_t'):
                             lin = f'{stream}.{i}.{a}.qkv'
                             self.Pk[lin] = ops.rows_pack_nk(self.Wn[lin])
@@ -439,6 +443,8 @@ class Engine:
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode, drop=(dm[5], dm[6]))
         else:
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
+        if self.rawln and self.proj_mlp and nxt is not None:      # no-grad: proj + residual run inside the MLP kernel that follows
+            return x, None, dict(o=o, proj=f'{pre}.{attn}.proj')
         o_op = self._mm(o)      # (bf16x3: the operand planes are kept for the weight gradient too -- o itself stays fp32 for the attention backward)
         y, ln_y = self._resid_gemm(o_op, f'{pre}.{attn}.proj', x, dm, pre, nxt)
         if self.fold:      # backward needs xhat and rstd only: the fp32 sub-layer input is not kept
@@ -455,8 +461,12 @@ class Engine:
         if self.rawln:                # no-grad: the whole sub-layer is one kernel; the hidden never reaches HBM, the operand is bf16(x) made in the kernel
             lin = f'{pre}.{mlp}.fc1'
             y = self._f(M, C)
-            ops.mlp_fused_fwd(None, True, self.Pk[f'{pre}.{mlp}'], self.Bf[lin], P[f'{pre}.{mlp}.fc2.bias'], self.Rs[lin], x, y, None,
-                              cfg.eps, None, None)
+            if isinstance(ln, dict):      # x + proj(o) first, in the same kernel
+                ops.proj_mlp_fused_fwd(ln['o'], self.Pk[f'{pre}.{mlp}'], P[ln['proj'] + '.bias'], self.Bf[lin], P[f'{pre}.{mlp}.fc2.bias'],
+                                       self.Rs[lin], x, y, cfg.eps)
+            else:
+                ops.mlp_fused_fwd(None, True, self.Pk[f'{pre}.{mlp}'], self.Bf[lin], P[f'{pre}.{mlp}.fc2.bias'], self.Rs[lin], x, y, None,
+                                  cfg.eps, None, None)
             return y, None, None
         if ln is not None:            # LayerNorm(x) came with x from the residual GEMM of the previous sub-layer
             xn, mean, rstd = ln

@@ -50,6 +50,9 @@ SIGNATURES = {
     'mbx_gemm_nt_rawln': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
     'mbx_mlp_pack_bytes': (_sz, [_i, _i]),
     'mbx_mlp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'mbx_proj_mlp_pack_bytes': (_sz, [_i, _i]),
+    'mbx_proj_mlp_pack_weights': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'mbx_proj_mlp_fused_fwd': (_i, [_vp] * 8 + [_f, _i, _i, _i, _vp]),
     'mbx_mlp_fused_fwd': (_i, [_vp, _i] + [_vp] * 7 + [_f, _vp, _vp, _i, _i, _i, _vp]),
     'mbx_rows_pack_bytes': (_sz, [_i, _i]),
     'mbx_rows_pack_nk': (_i, [_vp, _vp, _i, _i, _vp]),
@@ -285,6 +288,19 @@ class HipOps:
         packed = torch.empty(int(self.lib.mbx_mlp_pack_bytes(Cc, hidden)), dtype=torch.uint8, device=w1_t.device)
         self._ck(self.lib.mbx_mlp_pack_weights(_p(w1_t), _p(w2_t), _p(packed), Cc, hidden, self._stream()))
         return packed
+
+    def proj_mlp_pack_weights(self, wp_t, w1_t, w2_t):
+        """attn.proj [C, C], fc1 [hidden, C] (folded) and fc2 [C, hidden] (bf16) -> the fragment stream of mbx_proj_mlp_fused_fwd."""
+        hidden, Cc = w1_t.shape
+        packed = torch.empty(int(self.lib.mbx_proj_mlp_pack_bytes(Cc, hidden)), dtype=torch.uint8, device=w1_t.device)
+        self._ck(self.lib.mbx_proj_mlp_pack_weights(_p(wp_t), _p(w1_t), _p(w2_t), _p(packed), Cc, hidden, self._stream()))
+        return packed
+
+    def proj_mlp_fused_fwd(self, o_t, packed, bp, b1, b2, rsum, resid, y, eps):
+        """y = y1 + fc2(gelu(fc1(LayerNorm(y1)))), y1 = resid + o . Wp^T + bp: attention proj + residual + the whole MLP sub-layer, one kernel."""
+        M, Cc = resid.shape
+        self._ck(self.lib.mbx_proj_mlp_fused_fwd(_p(o_t), _p(packed), _p(bp), _p(b1), _p(b2), _p(rsum), _p(resid), _p(y), float(eps), M, Cc,
+                                                 b1.shape[0], self._stream()))
 
     def mlp_fused_fwd(self, a_t, raw_in, packed, b1, b2, rsum, resid, y, y_t, eps, mean, rstd):
         """a_t = None: the raw operand is made in the kernel from the fp32 rows of `resid`."""

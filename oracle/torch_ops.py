@@ -268,6 +268,20 @@ class MockOps:
         acc = x.to(packed.dtype).float() @ packed.float().t()
         out_t.copy_((rs * (acc - mu * rsum) + bias).to(out_t.dtype))
 
+    def proj_mlp_pack_weights(self, wp_t, w1_t, w2_t):
+        self._log('proj_mlp_pack_weights')
+        return (wp_t, w1_t, w2_t)
+
+    def proj_mlp_fused_fwd(self, o_t, packed, bp, b1, b2, rsum, resid, y, eps):
+        """mbx_proj_mlp_fused_fwd: y1 = resid + o . Wp^T + bp (fp32), then the fused MLP on y1 with its operand T(y1) and the statistics of
+        the fp32 rows of y1."""
+        self._log('proj_mlp_fused_fwd')
+        wp_t, w1_t, w2_t = packed
+        y1 = resid + o_t.float() @ wp_t.float().t() + bp
+        self.calls.append('_inner')
+        self.mlp_fused_fwd(None, True, (w1_t, w2_t), b1, b2, rsum, y1, y, None, eps, None, None)
+        del self.calls[-2:]
+
     def mlp_fused_fwd(self, a_t, raw_in, packed, b1, b2, rsum, resid, y, y_t, eps, mean, rstd):
         """y = resid + fc2(gelu(fc1)), fc1 = a . W1^T + b1 (raw_in = 0: a is the normalised operand) or
         rstd_a (a . W1^T - mean_a rsum) + b1 with (mean_a, rstd_a) the statistics of the bf16 rows of a (raw_in = 1);

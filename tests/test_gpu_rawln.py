@@ -122,3 +122,34 @@ def test_gemm_nt_rawln(ops, M, N, K):
     # and it is the Linear behind the LayerNorm: against LayerNorm(y) . w^T + bias taken in fp32 from the fp32 rows
     exact = ((yrow - mean[:, None]) * rstd[:, None]) @ w.float().t() + bias
     check(f'gemm_nt_rawln.vs_layernorm.{M}x{N}x{K}', out, exact, 1e-2)
+
+
+@pytest.mark.parametrize('M,C,hidden', [(1000, 512, 1024), (128 * 3 + 5, 256, 1024), (4131, 512, 1024), (77, 512, 128), (2 * 243 * 17, 256, 1024)])
+def test_proj_mlp_fused(ops, M, C, hidden):
+    """mbx_proj_mlp_fused_fwd: attention proj + residual + LayerNorm + fc1 + GELU + fc2 + residual in one kernel, against the torch
+    restatement (the proj product in fp32, then the fused-MLP restatement on it)."""
+    eps = 1e-6
+    x = rnd(M, C, seed=1) * (0.5 + rnd(M, 1, seed=7).abs()) + 0.7 * rnd(M, 1, seed=8)
+    o = rnd(M, C, seed=9, dtype=BF)
+    wp = rnd(C, C, seed=10, dtype=BF, scale=0.05)
+    w1, w2 = rnd(hidden, C, seed=2, dtype=BF, scale=0.06), rnd(C, hidden, seed=3, dtype=BF, scale=0.04)
+    bp, b1, b2 = rnd(C, seed=11, scale=0.3), rnd(hidden, seed=4, scale=0.3), rnd(C, seed=5, scale=0.3)
+    rsum = w1.float().sum(1)
+    packed = ops.proj_mlp_pack_weights(wp, w1, w2)
+    y = torch.full((M, C), float('nan'), device=DEV)
+    y2 = torch.empty(M, C, device=DEV)
+    ops.proj_mlp_fused_fwd(o, packed, bp, b1, b2, rsum, x, y, eps)
+    MockOps().proj_mlp_fused_fwd(o, (wp, w1, w2), bp, b1, b2, rsum, x, y2, eps)
+    tag = f'C{C}.h{hidden}.M{M}'
+    check(f'proj_mlp_fused.y.{tag}', y, y2, 2e-4)
+    check(f'proj_mlp_fused.branch.{tag}', y - x, y2 - x, 1e-3)
+    # the two-kernel form of the same sub-layer pair: proj + residual (fp32 out), then the fused MLP from those rows
+    y1, y3 = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    if M >= 256:
+        ops.gemm_nt(o, wp, bp, 2, out_f=y1, resid=x)
+        ops.mlp_fused_fwd(None, True, ops.mlp_pack_weights(w1, w2), b1, b2, rsum, y1, y3, None, eps, None, None)
+        check(f'proj_mlp_fused.vs_two_kernels.{tag}', y, y3, 2e-4)
+    # in place (y aliases resid)
+    xin = x.clone()
+    ops.proj_mlp_fused_fwd(o, packed, bp, b1, b2, rsum, xin, xin, eps)
+    assert torch.equal(xin, y)

@@ -7,6 +7,8 @@ layout, and the drop-in module API.  The reference numbers come from tests/golde
 (minted from the real reference model's autograd)."""
 import numpy as np
 import pytest
+import os
+
 import torch
 
 from motionbert_amd import model as M
@@ -115,9 +117,9 @@ def test_no_grad_saves_nothing_and_frozen_params_get_none():
 
 @pytest.mark.parametrize('name', ['tiny_default', 'tiny_trained'])
 def test_no_grad_raw_operand_sequencing(name):
-    """The no-grad path of a Block: 4 launches per attention + MLP pair -- qkv as a row-owner GEMM that makes operand and LayerNorm
-    statistics from the fp32 rows (rows_gemm.ln), attention, proj + residual, the fused MLP (operand from the fp32 rows too) -- no
-    LayerNorm pass, no bf16 copy of the residual stream; against the reference output and against the training-path sequencing."""
+    """The no-grad path of a Block: 3 launches per attention + MLP pair -- qkv as a row-owner GEMM that makes operand and LayerNorm
+    statistics from the fp32 rows (rows_gemm.ln), attention, and ONE kernel for proj + residual + LayerNorm + fc1 + GELU + fc2 + residual
+    -- no LayerNorm pass, no bf16 copy of the residual stream; against the reference output and against the training-path sequencing."""
     z, cfg = load_golden(name)
     model = build_model(cfg)
     _load(model, z)
@@ -132,17 +134,28 @@ def test_no_grad_raw_operand_sequencing(name):
     assert rel_l2(out.numpy(), z['out']) < 5e-6 and rel_l2(out_plain.numpy(), z['out']) < 2e-6
     assert rel_l2(rep.numpy(), z['rep']) < 5e-6
     depth = cfg['depth']
-    # per level: 2 Blocks x 2 x (qkv from the fp32 rows, proj + residual, fused MLP)
-    assert ops.calls.count('mlp_fused_fwd.from_x') == ops.calls.count('mlp_pack_weights') == 4 * depth and 'mlp_fused_fwd' not in ops.calls
+    # per level: 2 Blocks x 2 x (qkv from the fp32 rows, attention, proj + residual + MLP in one kernel)
+    assert ops.calls.count('proj_mlp_fused_fwd') == ops.calls.count('proj_mlp_pack_weights') == 4 * depth
+    assert not any(c.startswith('mlp_fused_fwd') or c == 'mlp_pack_weights' for c in ops.calls)
     assert ops.calls.count('rows_gemm.ln') == ops.calls.count('rows_pack_nk') == 4 * depth
-    assert ops.calls.count('gemm_nt.2') == 4 * depth
+    assert ops.calls.count('gemm_nt.2') == 0                                          # no stand-alone proj + residual GEMM
+    # the three-kernel form (proj + residual as its own GEMM, then the fused MLP on its fp32 output) behind the A/B switch
+    os.environ['MBX_PROJ_MLP'] = '0'
+    try:
+        ops3 = MockOps()
+        with torch.no_grad():
+            out3 = M.run(ops3, model, x)
+    finally:
+        del os.environ['MBX_PROJ_MLP']
+    assert rel_l2(out3.numpy(), z['out']) < 5e-6
+    assert ops3.calls.count('mlp_fused_fwd.from_x') == ops3.calls.count('mlp_pack_weights') == 4 * depth and ops3.calls.count('gemm_nt.2') == 4 * depth
     assert ops.calls.count('gemm_nt.0') == ops.calls.count('gemm_nt.1') == 0          # no qkv / fc1 / fc2 launches of the training path
     assert ops.calls.count('layernorm_fwd') == 0                                      # (the final LayerNorm is part of the head kernel)
     assert not any(c.startswith('mlp_fused') for c in ops_plain.calls) and ops_plain.calls.count('gemm_nt.1') == 4 * depth
     # with gradients enabled the training sequencing runs, whatever the provider offers
     ops_g = MockOps()
     M.run(ops_g, model, x.clone().requires_grad_(True)).sum().backward()
-    assert not any(c.startswith('mlp_fused') or c.startswith('rows_') for c in ops_g.calls)
+    assert not any(c.startswith('mlp_fused') or c.startswith('rows_') or c.startswith('proj_mlp') for c in ops_g.calls)
 
 
 def test_average_fusion_variant():
