@@ -325,7 +325,7 @@ class Engine:
                 x_st, sv_st = self._block_fwd(h, f'blocks_st.{i}', 'st', need_grad, ln_st)
                 x_ts, sv_ts = self._block_fwd(h, f'blocks_ts.{i}', 'ts', need_grad, ln_ts)
             hn = self._f(M, C)
-            if fuse_ln:
+            if fuse_ln and not (self.rawln and i + 1 < cfg.depth):      # (no-grad: the next level's consumers read the fp32 rows themselves)
                 # the fusion kernel also normalises its output for its consumers: the first LayerNorm of both blocks of the next
                 # level (one mean / rstd for the two), or the final `norm` after the last level
                 alpha, mean, rstd = self._f(M, 2), self._f(M), self._f(M)
