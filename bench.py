@@ -548,7 +548,8 @@ def main():
                      note='exposed = time the compute stream waits for the outstanding bucket all-reduces at the end of backward (HIP events '
                           'around the wait, rank 0, mean over the timed steps); single-GPU leg = the same step on the bare replica, no '
                           'gradient exchange, max over ranks; efficiency = single-GPU ms / N-GPU ms (weak scaling)')
-        log(f'multi-GPU diagnostics: {multi}')
+        if rank == 0:
+            log(f'multi-GPU diagnostics: {multi}')
 
     # ---- BASELINE config 1 beside the headline: the same model and batch forward-only (eval, no_grad), rank 0 at N=1
     fwd_only = None
