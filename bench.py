@@ -582,13 +582,13 @@ def main():
                 step(); step()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(3):
+                for _ in range(5):
                     step()
                 torch.cuda.synchronize()
-                pdt = (time.perf_counter() - t1) / 3
+                pdt = (time.perf_counter() - t1) / 5
                 gate_modes[prec] = dict(value=round(B / pdt, 1), unit='clips/s', ms_per_step=round(pdt * 1e3, 2),
                                         model_tflops=round(3.0 * model_flops_fwd(FULL, T) * B / pdt / 1e12, 1),
-                                        sample='same train step (fwd + bwd + AdamW), 3 timed steps after 2 warm-ups',
+                                        sample='same train step (fwd + bwd + AdamW), 5 timed steps after 2 warm-ups',
                                         parity='end-to-end output within 1e-3 of the reference (tests/test_gpu_model.py, fp32-class modes)')
                 log(f'{prec}: {pdt * 1e3:.1f} ms/step, {B / pdt:.1f} clips/s')
             except Exception as e:   # e.g. out of memory on a smaller device: report, do not fail the headline
@@ -663,11 +663,11 @@ def main():
             step256()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(5):
                 step256()
             torch.cuda.synchronize()
-            d256 = (time.perf_counter() - t1) / 2
-            full256 = dict(workload='full model train step (fwd + loss + bwd + AdamW), 256 clips x 243 frames on ONE GPU, recompute mode, 2 timed steps after 1 warm-up',
+            d256 = (time.perf_counter() - t1) / 5
+            full256 = dict(workload='full model train step (fwd + loss + bwd + AdamW), 256 clips x 243 frames on ONE GPU, recompute mode, 5 timed steps after 1 warm-up',
                            ms_per_step=round(d256 * 1e3, 1), clips_per_s=round(256 / d256, 1), model_tflops=round(3.0 * model_flops_fwd(FULL, T) * 256 / d256 / 1e12, 1),
                            peak_hbm_gib=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
             log(f'full model B=256 (recompute): {d256 * 1e3:.0f} ms/step, {256 / d256:.1f} clips/s, peak HBM {full256["peak_hbm_gib"]} GiB')
@@ -728,10 +728,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras and args.precision == 'bf16' and args.workload == 'pose':
         try:
             macro, frames, fl4 = make_pretrain(model, model, opt, B, J, rank, dev)
-            d4 = time_steps(macro, 3, 2)
+            d4 = time_steps(macro, 6, 2)
             cfg4 = dict(workload=f'config 4 (MB_pretrain.yaml): macro step = 2D batch [{B},30,17,3] (mask + noise, loss_2d_weighted) + 2D batch [{B},81,17,3] '
                                  f'(mask, loss_2d_weighted) + 3D batch [{B},243,17,3] (mask + noise, pose losses): three fwd + bwd + AdamW steps, augment2D / losses '
-                                 'as device kernels; 3 timed macro steps after 2 warm-ups',
+                                 'as device kernels; 6 timed macro steps after 2 warm-ups',
                         ms_per_macro_step=round(d4 * 1e3, 2), frames_per_s=round(frames / d4, 1), clips243_equiv_per_s=round(frames / 243.0 / d4, 1),
                         model_tflops=round(fl4 / d4 / 1e12, 1))
             log(f'config 4 (pretrain macro step): {d4 * 1e3:.1f} ms, {frames / 243.0 / d4:.1f} 243-frame-equivalent clips/s')
@@ -745,9 +745,9 @@ def main():
             m5 = DSTformer(norm_layer=partial(nn.LayerNorm, eps=1e-6), **FULL).to(dev)
             m5.precision = args.precision
             fn5, st5, fl5 = make_action(m5, 32, J, rank, dev, distributed=False)
-            d5 = time_steps(fn5, 3, 2)
+            d5 = time_steps(fn5, 8, 2)
             cfg5 = dict(workload='config 5 (MB_ft_NTU60_xsub.yaml): ActionNet step on [32,2,243,17,3] (backbone batch 64), dropout 0.5 + means fused in the '
-                                 'backbone tail, head 8704->2048->60, cross-entropy, two flat AdamW groups (lr 1e-4 / 1e-3); 3 timed steps after 2 warm-ups',
+                                 'backbone tail, head 8704->2048->60, cross-entropy, two flat AdamW groups (lr 1e-4 / 1e-3); 8 timed steps after 2 warm-ups',
                         ms_per_step=round(d5 * 1e3, 2), samples_per_s=round(32 / d5, 1), clips_per_s=round(64 / d5, 1), model_tflops=round(fl5 / d5 / 1e12, 1))
             log(f'config 5 (ActionNet step): {d5 * 1e3:.1f} ms, {64 / d5:.1f} clips/s')
             del fn5, st5, m5
