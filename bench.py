@@ -247,7 +247,7 @@ HBM_PEAK_TBS, HBM_ACHIEVABLE_TBS = 8.0, 6.3      # MI355X_MICROARCH.md: spec / m
 
 def pmc_traffic_bytes(B, T, precision):
     """HBM bytes per launch of the dominant kernel family.  Hardware counters cannot be read from inside the process:
-    they come from separate `rocprofv3 --pmc` passes of this very command (tools/bench_pmc.sh; FETCH_SIZE x2 on gfx950 +
+    they come from separate `rocprofv3 --pmc` passes of this very command (tools/gpu_session.sh profiles; FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, as the micro-architecture guide prescribes), summarised by tools/pmc_table.py into profiles/.  The number
     is therefore STATIC (taken from the committed table of this round's kernels, named in `traffic_source`), reported
     only for the configuration the table was taken on, otherwise null."""

@@ -1,4 +1,4 @@
-"""Merge the three PMC passes of tools/bench_pmc.sh (gpurun_out/pmc_bench_{mfma,fetch,write}.txt) and the kernel-trace
+"""Merge the three PMC passes of tools/gpu_session.sh profiles (gpurun_out/pmc_bench_{mfma,fetch,write}.txt) and the kernel-trace
 summary into one per-kernel table (the format bench.py's `roofline.traffic` reads).
 
     python tools/pmc_table.py gpurun_out profiles/r01_kernel_stats_v6_singlestream.txt > profiles/r01_pmc_bench_v6.txt

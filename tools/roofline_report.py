@@ -25,7 +25,7 @@ def main(outdir, stats):
     once = [v for k, v in calls.items() if 'embed_fwd' in k or 'head_fwd' in k]
     steps = max(1, once[0] if once else min(calls.values()))       # launches of a once-per-step kernel = steps in the trace
     print('# per-kernel roofline, 64 clips x 243 frames, bf16, one stream (tools/roofline_report.py; inputs: the kernel trace and the three PMC passes of')
-    print('# tools/gpu_profiles.sh).  flops = SQ_INSTS_MFMA x 32768; bytes = FETCH_SIZE x 2 + WRITE_SIZE; bound = min(2500 TF/s, flop/byte x 8 TB/s).')
+    print('# tools/gpu_session.sh profiles).  flops = SQ_INSTS_MFMA x 32768; bytes = FETCH_SIZE x 2 + WRITE_SIZE; bound = min(2500 TF/s, flop/byte x 8 TB/s).')
     print(f'{"kernel":58s} {"/step":>5s} {"us":>7s} {"TF/s":>7s} {"TB/s":>6s} {"fl/B":>6s} {"bound":>5s} {"roof":>7s} {"frac":>6s} {"of 5.5TB/s":>10s}')
     rows = []
     for k, c in mf.items():
