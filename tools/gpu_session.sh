@@ -24,7 +24,7 @@ for step in "$@"; do
   echo "== [$TAG] $step"
   case $kind in
     env) export "$arg" ;;
-    pytest) timeout 1700 python -m pytest tests -q -m gpu -p no:cacheprovider -x ${arg:+-k "$(sp "$arg")"} 2>&1 | out pytest$n 8 300 ;;
+    pytest) timeout 1700 python -m pytest tests -q -m gpu -p no:cacheprovider ${arg:+-k "$(sp "$arg")"} 2>&1 | out pytest$n 8 300 ;;
     file) f=${arg%%:*}; k=""; [[ "$arg" == *:* ]] && k=${arg#*:}; timeout 1700 python -m pytest "$f" -q -p no:cacheprovider -x ${k:+-k "$(sp "$k")"} 2>&1 | out file$n 8 300 ;;
     bench) timeout 900 python bench.py $(sp "${arg:---no-cpu-baseline}") 2>gpurun_out/${TAG}_bench$n.log | out bench$n 2 4000 ;;
     block) timeout 600 python bench.py --block 2>/dev/null | out block$n 1 600 ;;
