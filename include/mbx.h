@@ -350,6 +350,14 @@ int mbx_embed_fwd_tta(const float* x, const int* perm, const float* w, const flo
                       float* h, int B, int T, int J, int Din, int C, void* stream);
 int mbx_flip_average(const float* out2, const int* perm, float* out, int B, int T, int J, int D, void* stream);
 
+/* ---- measurement aid (bench.py `roofline.sustained_mfma_tflops`; not part of the model) --------------------------------------------
+ * The bf16 MFMA rate the part sustains under its power cap with nothing but v_mfma_f32_32x32x16_bf16 in the loop (pseudo-random
+ * operands; n_wg workgroups of 4 waves, `iters` x 16 MFMAs per wave).  ws: >= mbx_mfma_probe_ws(n_wg) bytes = a float sink
+ * [n_wg * 256] followed by int64 [n_wg][2] = {shader cycles, 100 MHz real-time ticks} of every workgroup's loop (effective clock).
+ * *flops = the matrix FLOPs of the launch; the caller times it with HIP events. */
+size_t mbx_mfma_probe_ws(int n_wg);
+int mbx_mfma_probe(void* ws, int n_wg, int iters, unsigned seed, double* flops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

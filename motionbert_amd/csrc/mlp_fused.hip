@@ -110,6 +110,16 @@ __device__ __forceinline__ float2 ge_bias_ld(const char* p) {
 // (the accumulator layout holds columns 8 q + 4 g + e of a token, an operand fragment 8 consecutive ones: one v_permlane32_swap
 // per register pair) and takes the LayerNorm statistics of y1 from the same values.  y1 never exists in HBM (- 8 bytes per element),
 // one launch less per Block half.
+// Diagnostic builds only (tools/build_variants.py name -DMBX_MLP_TRACE; tools/mlp_trace.py): 16 time stamps per workgroup (wave 0),
+// s_memrealtime ticks (100 MHz) in slots 0..14, the shader-cycle counter at entry / exit in the upper halves of slots 0 / 14, the
+// hardware id in slot 15.  The buffer address comes from the environment variable MBX_TRACE_BUF of the host process.
+#ifdef MBX_MLP_TRACE
+__device__ long long* g_mlp_trace;
+#define MF_TS(slot_) do { if (tr_on) tr[slot_] = (long long)wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MF_TS(slot_) do { } while (0)
+#endif
+
 template <int C, bool PROJ = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restrict__ xh, const char* __restrict__ wpk,
                                                            const float* __restrict__ b1, const float* __restrict__ b2,
@@ -141,6 +151,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     constexpr int NPS = PROJ ? KS * NT2 / 32 : 0;   // stages of the proj part of the stream
     const int nch = hidden / F_CH, NS = nch * 2 * S2;
     float* const bps = reinterpret_cast<float*>(smem + F_RING + (size_t)(2 * hidden + C) * 4 + (C == 512 ? 4 * 4096 : 0));   // PROJ: bp [C] behind everything else
+#ifdef MBX_MLP_TRACE
+    const bool tr_on = g_mlp_trace != nullptr && tid == 0;
+    long long* const tr = g_mlp_trace + (size_t)blockIdx.x * 16;
+    if (tr_on) { tr[15] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); tr[16 * gridDim.x + blockIdx.x] = (long long)__builtin_readcyclecounter(); }
+#endif
+    MF_TS(0);
 
     // (Measured and dropped, round 4: a start stagger of the first workgroup of every CU by k/8 of a tile period, to run the memory
     // phases of some CUs under the compute phases of the others -- 101.2 us per tile round with and 102.7-103.3 without, i.e. null:
@@ -190,7 +206,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MF_TS(1);
     __builtin_amdgcn_s_barrier();                  // the biases are in LDS
+    MF_TS(2);
 
     // ---- the fc2 accumulators start from residual + bias: y = x + b2 + G . W2^T is then what the MFMAs leave, and the epilogue
     // only writes.  Per 256-column half the wave's 32 residual rows arrive in its LDS image by LDS-DMA (one instruction = one row's
@@ -226,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             acc2[nt] = t;
             asm volatile("s_nop 1" : "+a"(acc2[nt]));             // a whole tile at a time into accumulator registers, where it stays
         }
+        MF_TS(3 + hh);
         if (from_x) {
 #pragma unroll
             for (int sl = 0; sl < 16; ++sl) {                     // k-steps 16 hh + sl: eight consecutive channels of row i per lane
@@ -251,6 +270,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // every wave is done with its image: the ring is free
+    MF_TS(5);
 
     // ---- weight stream -------------------------------------------------------------------------------------------------------
     // stage sequence q -> byte offset in the packed stream:  A(0) | A(1) B(0) | A(2) B(1) | ... | A(n-1) B(n-2) | B(n-1)
@@ -297,6 +317,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         MF_ISSUE1(s2, 2, 1);
     }
     MF_SYNC(10);                                                // stage 0 is in LDS
+    MF_TS(6);
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
 
@@ -423,6 +444,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                 }
             MF_STAGE(MMA_P, HOOK_NONE);
         }
+        MF_TS(7);
         // ---- y1 sits in the accumulators: operand fragments and LayerNorm statistics from them.  Lane (i, g) holds columns
         // 32 nt + 8 q + 4 g + e of token i in acc2[nt][4 q + e]; fragment s = 2 nt + h wants its columns 16 s + 8 g + [0, 8): quads
         // q = 2 h + g of BOTH half waves.  v_permlane32_swap(a, b) exchanges a's upper half with b's lower half: from
@@ -468,6 +490,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
 #pragma unroll
         for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
     }
+    MF_TS(8);
     // A(0), gelu(0): the only GELU that overlaps nothing
     MF_PART_A();
     MFMA_PAD_V(acc1[0], acc1[1]);
@@ -479,6 +502,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                         G[3] = G[2]; G[2] = G[1]; G[1] = G[0]; G[0] = G[4];                                                         \
                         asm volatile("s_nop 3" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3])); } while (0)
     G_ROTATE();
+    MF_TS(9);
     for (int c = 1; c < nch; ++c) {
         MF_PART_A();                       // A(c)
         gc = c;
@@ -487,8 +511,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_G1);
         G_ROTATE();
     }
+    MF_TS(10);
     MF_STAGE(MMA_B0, HOOK_NONE);           // B(n - 1)
     if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_NONE);
+    MF_TS(11);
 
     // ---- epilogue: the accumulators hold y.  Statistics per lane (= half a row) as shifted sums, the halves joined by Chan's
     // formula; then per 256-column half the accumulators go through the wave's LDS image and leave row-major: one instruction =
@@ -496,6 +522,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     if (MBX_MLP_DBG & 8) return;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-read tail stages have landed, the last prefetches returned
     __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring
+    MF_TS(12);
 #pragma unroll
     for (int t = 0; t < NT2; ++t) MFMA_PAD_A(acc2[t]);
     // (lane-derived values are re-derived from an opaque copy of the thread index: otherwise the compiler carries a dozen of them
@@ -538,6 +565,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                 *reinterpret_cast<uint2*>(brow + (size_t)r * C + lane_e * 4) = make_uint2(pack_bf2(t.x, t.y), pack_bf2(t.z, t.w));
         }
     }
+#ifdef MBX_MLP_TRACE
+    MF_TS(13);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MF_TS(14);
+    if (tr_on) tr[16 * gridDim.x + gridDim.x + blockIdx.x] = (long long)__builtin_readcyclecounter();
+#endif
     if (want_stats) {
         constexpr float nh = (float)(C / 2);                          // values per lane
         const float mean_h = sh + s1 / nh, m2_h = s2 - s1 * s1 / nh;  // this half row: mean, sum of squared deviations
@@ -572,6 +605,12 @@ static int launch_mlp_fused(const void* a, const void* packed, const float* b1, 
     const size_t shm = F_RING + (size_t)(2 * hidden + C) * sizeof(float) + (C == 512 ? 4 * 4096 : 0) + (PROJ ? C * sizeof(float) : 0);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<C, PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
         return mbx_set_error("mlp_fused_fwd: cannot reserve %zu bytes of LDS", shm);
+#ifdef MBX_MLP_TRACE
+    {
+        static long long* const tb = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mlp_trace), &tb, sizeof(tb), 0, hipMemcpyHostToDevice, s);
+    }
+#endif
     hipLaunchKernelGGL((mlp_fused_kernel<C, PROJ>), dim3((M + F_BM - 1) / F_BM), dim3(256), shm, s, (const bf16_t*)a, (const char*)packed, b1, b2,
                        rsum, raw_in, resid, y, (bf16_t*)yb, eps, mean, rstd, M, hidden, bp);
     MBX_LAUNCH_CHECK("mlp_fused_fwd");

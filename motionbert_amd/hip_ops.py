@@ -94,6 +94,8 @@ SIGNATURES = {
     'mbx_augment2d': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp] + [_f] * 8 + [_i, C.c_uint64, _vp]),
     'mbx_embed_fwd_tta': (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     'mbx_flip_average': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mbx_mfma_probe_ws': (_sz, [_i]),
+    'mbx_mfma_probe': (_i, [_vp, _i, _i, C.c_uint, _vp, _vp]),
     'mbx_adamw_step': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _i, _vp]),
 }
 
@@ -336,6 +338,31 @@ class HipOps:
         M, K = a_t.shape
         self._ck(self.lib.mbx_gemm_nt_rawln(_p(a_t), _p(w_t), _p(bias), _p(rsum), _p(mean), _p(rstd), _p(out_t), M, w_t.shape[0], K,
                                             self._stream()))
+
+    # ------------------------------------------------------------------ measurement aid (bench.py, tools/clock_power.py)
+    def mfma_probe(self, seconds: float = 0.25, wgs_per_cu: int = 1, device=None):
+        """The bf16 MFMA rate the part sustains with nothing but MFMAs in the loop (random operands), run for about `seconds` so
+        that the power management has settled: dict(tflops, clock_ghz, ms).  `clock_ghz` = shader cycles / real time inside the
+        kernel (median over workgroups)."""
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        n_wg = cus * wgs_per_cu
+        ws = torch.zeros(int(self.lib.mbx_mfma_probe_ws(n_wg)), dtype=torch.uint8, device=dev)
+        flops = C.c_double(0.0)
+
+        def run(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._ck(self.lib.mbx_mfma_probe(_p(ws), n_wg, iters, 1234, C.byref(flops), self._stream()))
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+        ms = run(20000)                                            # calibrate, then one long launch
+        iters = max(20000, int(20000 * seconds * 1e3 / max(ms, 1e-3)))
+        ms = run(iters)
+        st = ws[n_wg * 1024:].view(torch.int64).view(n_wg, 2).cpu().double()
+        clock = float((st[:, 0] / (st[:, 1] * 1e-8)).median()) / 1e9
+        return dict(tflops=flops.value / ms / 1e9, clock_ghz=clock, ms=ms, iters=iters, wgs_per_cu=wgs_per_cu)
 
     # ------------------------------------------------------------------ residual GEMM + the next LayerNorm (bf16 path)
     def can_fuse_resid_ln(self, tdtype, N: int, device=None) -> bool:
