@@ -1053,11 +1053,7 @@ static int check_attn_args(const char* who, int B, int T, int J, int H, int hd, 
 template <typename K>
 static int set_lds(K kernel, size_t bytes, const char* who) {
     if (bytes > 160 * 1024) return mbx_set_error("%s: needs %zu bytes of LDS (> 160 KiB)", who, bytes);
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return mbx_set_error("%s: hipFuncSetAttribute(%zu): %s", who, bytes, hipGetErrorString(e));
-    }
-    return 0;
+    return bytes > 64 * 1024 ? mbx_set_dyn_lds(reinterpret_cast<const void*>(kernel), bytes, who) : 0;
 }
 
 // p in [0, 1): 0 = no dropout (the kernels without the mask code)

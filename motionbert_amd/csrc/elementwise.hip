@@ -18,6 +18,44 @@ int mbx_set_error(const char* fmt, ...) {
     return 1;
 }
 extern "C" const char* mbx_last_error(void) { return g_err; }
+
+// ---- per-device launch properties (declared in mbx_common.h) --------------------------------------------------------------------
+// table of (kernel address, device) -> largest dynamic-LDS size already granted.  Open addressing over 512 slots, entries are only
+// ever added (there are < 100 kernel instantiations x a handful of devices); a slot is claimed by a compare-exchange on its key, its
+// size only grows.  A lost race costs one redundant hipFuncSetAttribute, never a missing one.
+#include <atomic>
+static std::atomic<uintptr_t> g_lds_key[512];
+static std::atomic<size_t> g_lds_size[512];
+int mbx_set_dyn_lds(const void* kernel, size_t bytes, const char* who) {
+    if (bytes > 160 * 1024) return mbx_set_error("%s: needs %zu bytes of LDS (> 160 KiB)", who, bytes);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uintptr_t key = (reinterpret_cast<uintptr_t>(kernel) << 6) ^ (uintptr_t)(dev + 1);
+    int slot = (int)((key * 0x9E3779B97F4A7C15ull) >> 55);      // 9 bits
+    for (int probe = 0; probe < 512; ++probe, slot = (slot + 1) & 511) {
+        uintptr_t k = g_lds_key[slot].load(std::memory_order_acquire);
+        if (k == 0 && g_lds_key[slot].compare_exchange_strong(k, key, std::memory_order_acq_rel)) k = key;
+        if (k != key) continue;
+        if (g_lds_size[slot].load(std::memory_order_acquire) >= bytes) return 0;
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return mbx_set_error("%s: hipFuncSetAttribute(%zu): %s", who, bytes, hipGetErrorString(e));
+        size_t cur = g_lds_size[slot].load(std::memory_order_relaxed);
+        while (cur < bytes && !g_lds_size[slot].compare_exchange_weak(cur, bytes, std::memory_order_release)) { }
+        return 0;
+    }
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);      // table full: as before
+    return e == hipSuccess ? 0 : mbx_set_error("%s: hipFuncSetAttribute(%zu): %s", who, bytes, hipGetErrorString(e));
+}
+static std::atomic<int> g_cus[64];
+int mbx_cu_count() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int c = g_cus[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    g_cus[dev].store(c, std::memory_order_relaxed);
+    return c;
+}
 extern "C" int mbx_version(void) { return 100; }
 
 static inline int clamp_grid(size_t want, int cap) { return (int)(want < (size_t)cap ? (want ? want : 1) : (size_t)cap); }

@@ -551,12 +551,7 @@ static int launch_gemm_tn_f32(const void* dy, const void* a, float* dw, float* d
     const int cps = (nchunks + splits - 1) / splits;
     float* part_w = splits == 1 ? dw : (float*)ws;
     float* part_b = db ? (splits == 1 ? db : (float*)ws + (size_t)splits * N * K) : nullptr;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TF_NST * TF_STAGE) != hipSuccess)
-            return mbx_set_error("gemm_tn: cannot reserve %d bytes of LDS", TF_NST * TF_STAGE);
-        attr = true;
-    }
+    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(gemm_tn_f32_kernel), TF_NST * TF_STAGE, "gemm_tn")) return 1;
     hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(8 * ntn * ntk * ((splits + 7) / 8)), dim3(256), TF_NST * TF_STAGE, s, (const float*)dy,
                        (const float*)a, part_w, part_b, M, N, K, ntk, cps, splits);
     MBX_LAUNCH_CHECK("gemm_tn_f32");

@@ -1032,9 +1032,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
 
 template <typename K>
 static int set_lds_attr(K kernel, size_t bytes, const char* who) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return mbx_set_error("%s: hipFuncSetAttribute(%zu): %s", who, bytes, hipGetErrorString(e));
-    return 0;
+    return mbx_set_dyn_lds(reinterpret_cast<const void*>(kernel), bytes, who);
 }
 
 static int launch_nt256(const void* a, const void* w, const float* bias, int epi, void* out_t, void* out2_t, float* out_f,

@@ -125,17 +125,21 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
     if constexpr (FROMX) {
         // the operand is bf16(x) rounded HERE from the fp32 rows of the residual stream, and the LayerNorm statistics are taken from
         // the same loads: lane (i, g) sees half of row i (shifted sums; the halves are joined below by Chan's formula)
+        // The operand is bf16(x - x[row][0]): LayerNorm does not see a shift of its row, and rounding the SHIFTED values keeps the
+        // rounding error proportional to the spread of the row instead of to its magnitude (a row with a large common offset would
+        // otherwise lose mean^2 / var of its precision).  The shift is the row's first element -- the s = 0 value of lane
+        // (i, 0), handed to lane (i, 1) by one permlane swap -- so both halves, and the row constants below, use the same one.
         const float* const ap = reinterpret_cast<const float*>(a) + (size_t)row * K + 8 * g;
         float xsh = 0.f, xs1 = 0.f, xs2 = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float4 lo = *reinterpret_cast<const float4*>(ap + 16 * s), hi = *reinterpret_cast<const float4*>(ap + 16 * s + 4);
-            if (s == 0) xsh = lo.x;
+            if (s == 0) xsh = wave_lower_half(lo.x);
             const float d[8] = {lo.x - xsh, lo.y - xsh, lo.z - xsh, lo.w - xsh, hi.x - xsh, hi.y - xsh, hi.z - xsh, hi.w - xsh};
             xs1 += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
 #pragma unroll
             for (int e = 0; e < 8; ++e) xs2 = fmaf(d[e], d[e], xs2);
-            X[s] = u32x4_t{pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w)};
+            X[s] = u32x4_t{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3]), pack_bf2(d[4], d[5]), pack_bf2(d[6], d[7])};
         }
         constexpr float nh = (float)(K / 2);
         const float mean_h = xsh + xs1 / nh, m2_h = xs2 - xs1 * xs1 / nh;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
         const float delta = mean_o - mean_h;
         const float var = fmaxf((m2_both + delta * delta * (nh * 0.5f)) / (float)K, 0.f);
         ln_rs = 1.0f / sqrtf(var + eps);
-        ln_k = -ln_rs * 0.5f * (mean_h + mean_o);
+        ln_k = -ln_rs * (0.5f * (mean_h + mean_o) - xsh);      // the mean of the shifted row
     } else {
         const bf16_t* const ap = reinterpret_cast<const bf16_t*>(a) + (size_t)row * K + 8 * g;
 #pragma unroll
@@ -297,15 +301,9 @@ template <int K, int EPI, bool FROMX>
 static int launch_rows_nk(const void* a, const void* packed, const float* bias, const float* rsum, const float* mean, const float* rstd,
                           void* out, float eps, int M, int N, hipStream_t s) {
     const size_t shm = R_RING + R_TB + (size_t)2 * N * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rows_nk_kernel<K, EPI, FROMX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
-        return mbx_set_error("rows_gemm_nk: cannot reserve %zu bytes of LDS", shm);
+    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_nk_kernel<K, EPI, FROMX>), shm, "rows_gemm_nk")) return 1;
     // whole rounds of the chip (two workgroups per CU) as whole tiles; the tiles of the last, partial round in column ranges
-    static int slots = 0;
-    if (slots == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        slots = 2 * cus;
-    }
+    const int slots = 2 * mbx_cu_count();
     const int tiles = (M + R_BM - 1) / R_BM, nch = N / R_CH;
     int nfull = tiles / slots * slots, parts = 1;
     for (int pp = 8; pp > 1; --pp)

@@ -26,6 +26,13 @@ int mbx_set_error(const char* fmt, ...);
         if (e_ != hipSuccess) return mbx_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// ---------------------------------------------------------------- per-device launch properties (elementwise.hip)
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device) instead of once per launch (host time on the B = 1 latency
+// path), and the CU count of the CURRENT device: both remembered in lock-free per-device tables -- launches come from the
+// main thread, the autograd engine's thread and DataParallel's replica threads, possibly for different devices.
+int mbx_set_dyn_lds(const void* kernel, size_t bytes, const char* who);
+int mbx_cu_count();
+
 // ---------------------------------------------------------------- diagnostics switches
 // The product library reads NO environment variables: every kernel choice is fixed at build time.  A/B variants and
 // ablation switches exist only in -DMBX_DIAG builds (tools/build_variants.py -> tools/variants/libmbx_*.so, loaded by the
@@ -124,6 +131,12 @@ template <typename Op> __device__ __forceinline__ float wave_halves(float v) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return Op::op(a, b);
+}
+// v[lane & 31] on every lane: the lower half wave's value, broadcast to the upper half (one v_permlane32_swap)
+__device__ __forceinline__ float wave_lower_half(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a;
 }
 __device__ __forceinline__ float wave_sum(float v) { return wave_reduce<WaveAdd>(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_reduce<WaveMax>(v); }

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                 const float4 xv = *reinterpret_cast<const float4*>(er + i * 1024 + (((ntl * 8 + 2 * qq + g) ^ (i & 15)) << 4));
                 t[4 * qq] = xv.x + bb.x; t[4 * qq + 1] = xv.y + bb.y; t[4 * qq + 2] = xv.z + bb.z; t[4 * qq + 3] = xv.w + bb.w;
                 if (from_x) {
-                    if (hh == 0 && ntl == 0 && qq == 0) xsh = xv.x;
+                    if (hh == 0 && ntl == 0 && qq == 0) xsh = wave_lower_half(xv.x);      // x[row][0] for both half rows (see below)
                     const float d0 = xv.x - xsh, d1 = xv.y - xsh, d2 = xv.z - xsh, d3 = xv.w - xsh;
                     xs1 += (d0 + d1) + (d2 + d3);
                     xs2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, xs2))));
@@ -250,7 +250,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             for (int sl = 0; sl < 16; ++sl) {                     // k-steps 16 hh + sl: eight consecutive channels of row i per lane
                 const float4 lo = *reinterpret_cast<const float4*>(er + i * 1024 + (((4 * sl + 2 * g) ^ (i & 15)) << 4));
                 const float4 hi = *reinterpret_cast<const float4*>(er + i * 1024 + (((4 * sl + 2 * g + 1) ^ (i & 15)) << 4));
-                X[hh * 16 + sl] = u32x4_t{pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w)};
+                // operand = bf16(x - x[row][0]): LayerNorm does not see the shift, and the rounding error then scales with the spread of
+                // the row, not with its magnitude (gemm_rows.hip, FROMX)
+                X[hh * 16 + sl] = u32x4_t{pack_bf2(lo.x - xsh, lo.y - xsh), pack_bf2(lo.z - xsh, lo.w - xsh), pack_bf2(hi.x - xsh, hi.y - xsh),
+                                          pack_bf2(hi.z - xsh, hi.w - xsh)};
             }
         }
     }
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         const float delta = mean_o - mean_h;
         const float var = fmaxf((m2_both + delta * delta * (nh * 0.5f)) / (float)C, 0.f);
         ln_rs = 1.0f / sqrtf(var + eps);
-        ln_k = -ln_rs * 0.5f * (mean_h + mean_o);
+        ln_k = -ln_rs * (0.5f * (mean_h + mean_o) - xsh);      // the mean of the shifted row
     }
     if constexpr (!PROJ) {                         // (PROJ: X is made after the proj product, below)
 #pragma unroll
@@ -451,18 +454,25 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         // (a, b) = registers e of quads (2 h, 2 h + 1) every lane gets its own quad's value of lane (i, 0) in a and of lane (i, 1) in b.
 #pragma unroll
         for (int t = 0; t < NT2; ++t) MFMA_PAD_A(acc2[t]);
-        float sh = 0.f, s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f;
+        // the operand is bf16(y1 - y1[row][0]) (LayerNorm does not see the shift; the rounding error then scales with the spread of
+        // the row, not with its magnitude -- gemm_rows.hip, FROMX): the shift of BOTH half rows is lane (i, 0)'s first value
+        float sh;
+        {
+            float v0 = acc2[0][0];
+            asm volatile("s_nop 1" : "+v"(v0));
+            sh = wave_lower_half(v0 - b2s[4 * g]);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             f32x16_t t = acc2[nt];                                 // y1 + b2 (the accumulators started from resid + bp + b2, so that the
-#pragma unroll                                                     // epilogue stays a pure read of them): take b2 off again
+#pragma unroll                                                     // epilogue stays a pure read of them): take b2 (and the shift) off again
             for (int qq = 0; qq < 4; ++qq) {
                 const float4 bb = *reinterpret_cast<const float4*>(b2s + nt * 32 + 8 * qq + 4 * g);
-                t[4 * qq] -= bb.x; t[4 * qq + 1] -= bb.y; t[4 * qq + 2] -= bb.z; t[4 * qq + 3] -= bb.w;
+                t[4 * qq] -= bb.x + sh; t[4 * qq + 1] -= bb.y + sh; t[4 * qq + 2] -= bb.z + sh; t[4 * qq + 3] -= bb.w + sh;
             }
-            if (nt == 0) sh = t[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float d = t[r] - sh; s1 += d; s2 = fmaf(d, d, s2); }
+            for (int r = 0; r < 16; ++r) { s1 += t[r]; s2 = fmaf(t[r], t[r], s2); }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float a[4], b[4];
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             const float delta = mean_o - mean_h;
             const float var = fmaxf((m2_both + delta * delta * (nh * 0.5f)) / (float)C, 0.f);
             ln_rs = 1.0f / sqrtf(var + eps);
-            ln_k = -ln_rs * 0.5f * (mean_h + mean_o);
+            ln_k = -ln_rs * (0.5f * (mean_h + mean_o) - sh);      // the mean of the shifted row
         }
 #pragma unroll
         for (int s = 0; s < XL; ++s) *reinterpret_cast<u32x4_t*>(xsp + s * 1024) = X[KS - XL + s];
@@ -603,8 +613,7 @@ static int launch_mlp_fused(const void* a, const void* packed, const float* b1, 
                             const float* resid, float* y, void* yb, float eps, float* mean, float* rstd, int M, int hidden, hipStream_t s,
                             const float* bp = nullptr) {
     const size_t shm = F_RING + (size_t)(2 * hidden + C) * sizeof(float) + (C == 512 ? 4 * 4096 : 0) + (PROJ ? C * sizeof(float) : 0);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<C, PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
-        return mbx_set_error("mlp_fused_fwd: cannot reserve %zu bytes of LDS", shm);
+    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(mlp_fused_kernel<C, PROJ>), shm, "mlp_fused_fwd")) return 1;
 #ifdef MBX_MLP_TRACE
     {
         static long long* const tb = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();

@@ -170,6 +170,7 @@ class Engine:
         self.rawln = False
         self.rawln_allowed = os.environ.get('MBX_RAWLN', '1') == '1'      # A/B switch: 0 = the training sequencing without saves
         self.Pk: Dict[str, torch.Tensor] = {}       # fc1 / fc2 of every MLP (with the proj in front of it) in the fragment order of the fused kernels
+        self.Pk_proj: Dict[str, str] = {}           # MLP -> the proj Linear packed in front of it (derived from ORDER)
         self.proj_mlp = os.environ.get('MBX_PROJ_MLP', '1') == '1' and hasattr(ops, 'proj_mlp_fused_fwd')      # A/B switch: 0 = proj + residual as its own GEMM
         # residual GEMM + the next LayerNorm forward in one launch (round 3, bf16 path; include/mbx.h): decided at the first forward
         # (the provider checks the device's workgroup -> XCD rule once).  Opt-in with MBX_RESID_LN=1: measured time-neutral at 64 clips
@@ -256,9 +257,36 @@ class Engine:
             return (torch.empty(shape, dtype=torch.bfloat16, device=self.dev), torch.empty(shape, dtype=torch.bfloat16, device=self.dev))
         return self._t(*shape)
 
+    def _weight_cache_key(self, need_grad: bool):
+        """Key of the prepared-weight cache of the no-grad path: the parameters' storage and version counters (every
+        in-place update -- optimizer.step(), FlatAdamW, load_state_dict -- bumps them) and everything that selects a format.  None =
+        do not cache: a backward follows (training re-prepares every step anyway), or a hipGraph is being captured (the re-pack has
+        to be part of the graph so that a replay picks up weights updated in place, graph.py).  Edits through `param.data` bypass the
+        version counters (as they bypass autograd's own checks): `hip_ops.get().weight_cache.clear()` after such an edit."""
+        if need_grad or not hasattr(self.ops, 'weight_cache') or self.dev.type != 'cuda' or torch.cuda.is_current_stream_capturing():
+            return None
+        return (tuple((p.data_ptr(), p._version) for p in self.P.values()), self.T, self.fold, self.rawln, self.proj_mlp, self.x3)
+
     def prepare_weights(self, need_grad: bool):
         """T-typed copies of every Linear weight (and their transposes when a backward follows); with LayerNorm folding the
-        qkv / fc1 weights are W diag(gamma) and come with their folded bias and row sums."""
+        qkv / fc1 weights are W diag(gamma) and come with their folded bias and row sums.  Under no_grad the prepared set is kept
+        on the kernel provider and reused as long as no parameter changed: an inference call then launches no fold / pack kernels
+        (at depth 5 they were ~60 small launches per forward, as many as a B = 1 forward has kernels of its own)."""
+        cfg, ops, P = self.cfg, self.ops, self.P
+        key = self._weight_cache_key(need_grad)
+        if key is not None:
+            hit = ops.weight_cache.get(self.dev.index)
+            # same storage + same versions is not enough: a NEW model built after the old one died gets the same addresses and the
+            # same (small) version numbers from the allocator -- the entry must be about these very tensor objects
+            if hit is not None and hit[0] == key and len(hit[1]) == len(P) and all(r() is p for r, p in zip(hit[1], P.values())):
+                self.Wn, self.Wt, self.Bf, self.Rs, self.Pk, self.Pk_proj = hit[2]
+                return
+        self._prepare_weights(need_grad)
+        if key is not None:
+            import weakref
+            ops.weight_cache[self.dev.index] = (key, [weakref.ref(p) for p in P.values()], (self.Wn, self.Wt, self.Bf, self.Rs, self.Pk, self.Pk_proj))
+
+    def _prepare_weights(self, need_grad: bool):
         cfg, ops, P = self.cfg, self.ops, self.P
         if self.fold:
             pairs = folded_pairs(cfg)
@@ -268,12 +296,18 @@ class Engine:
             self.Wn.update(fn)
             self.Wt.update(ft)
             if self.rawln:
-                for stream in ('blocks_st', 'blocks_ts'):
+                for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')):
                     for i in range(cfg.depth):
-                        for m, a in (('mlp_s', 'attn_s'), ('mlp_t', 'attn_t')):      # every MLP follows the attention of its own kind
+                        order = ORDER[kind]
+                        for sub, (typ, _norm, m, _mode) in enumerate(order):
+                            if typ != 'mlp':
+                                continue
                             pre = f'{stream}.{i}.{m}'
-                            if self.proj_mlp:
-                                self.Pk[pre] = ops.proj_mlp_pack_weights(self.Wn[f'{stream}.{i}.{a}.proj'], self.Wn[pre + '.fc1'], self.Wn[pre + '.fc2'])
+                            # the proj that runs in front of this MLP in the same kernel: the attention right before it in ORDER
+                            a = order[sub - 1][2] if sub > 0 and order[sub - 1][0] == 'attn' else None
+                            if self.proj_mlp and a is not None:
+                                self.Pk_proj[pre] = f'{stream}.{i}.{a}.proj'
+                                self.Pk[pre] = ops.proj_mlp_pack_weights(self.Wn[self.Pk_proj[pre]], self.Wn[pre + '.fc1'], self.Wn[pre + '.fc2'])
                             else:
                                 self.Pk[pre] = ops.mlp_pack_weights(self.Wn[pre + '.fc1'], self.Wn[pre + '.fc2'])
                         for a in ('attn_s', 'attn_t'):
@@ -386,16 +420,20 @@ class Engine:
 
     def _block_fwd(self, x, pre, kind, need_grad, ln=None):
         """`ln` = (xn, mean, rstd) of x when its producer already normalised it: the fusion kernel of the previous level for the
-        first sub-layer, the residual GEMM of the previous sub-layer for the others (`gemm_nt_resid_ln`)."""
+        first sub-layer, the residual GEMM of the previous sub-layer for the others (`gemm_nt_resid_ln`); never anything else."""
         svs = []
         order = ORDER[kind]
+        pend = None      # no-grad: an attention whose proj + residual has been left to the MLP kernel that follows: dict(o=, proj=)
         for sub, (typ, norm, mod, mode) in enumerate(order):
             nxt = order[sub + 1][1] if sub + 1 < len(order) else None      # the norm that reads this sub-layer's output
             if typ == 'attn':
-                x, sv, ln = self._attn_fwd(x, pre, norm, mod, mode, need_grad, sub, ln, nxt)
+                defer = self.rawln and self.proj_mlp and sub + 1 < len(order) and order[sub + 1][0] == 'mlp'
+                x, sv, ln, pend = self._attn_fwd(x, pre, norm, mod, mode, need_grad, sub, ln, nxt, defer_proj=defer)
             else:
-                x, sv, ln = self._mlp_fwd(x, pre, norm, mod, need_grad, sub, ln, nxt)
+                x, sv, ln = self._mlp_fwd(x, pre, norm, mod, need_grad, sub, ln, nxt, pending_proj=pend)
+                pend = None
             svs.append(sv)
+        assert pend is None, 'an attention deferred its proj to an MLP that never came'
         return x, svs
 
     def _resid_gemm(self, a, lin, x, dm, pre, nxt):
@@ -418,7 +456,7 @@ class Engine:
             ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])
         return y, None
 
-    def _attn_fwd(self, x, pre, norm, attn, mode, need_grad, sub=0, ln=None, nxt=None):
+    def _attn_fwd(self, x, pre, norm, attn, mode, need_grad, sub=0, ln=None, nxt=None, defer_proj=False):
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C = self.M, cfg.C
         qkv = self._t(M, 3 * C)
@@ -443,8 +481,8 @@ class Engine:
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode, drop=(dm[5], dm[6]))
         else:
             ops.attn_fwd(qkv, o, lse, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
-        if self.rawln and self.proj_mlp and nxt is not None:      # no-grad: proj + residual run inside the MLP kernel that follows
-            return x, None, dict(o=o, proj=f'{pre}.{attn}.proj')
+        if defer_proj:      # no-grad: proj + residual run inside the MLP kernel that follows
+            return x, None, None, dict(o=o, proj=f'{pre}.{attn}.proj')
         o_op = self._mm(o)      # (bf16x3: the operand planes are kept for the weight gradient too -- o itself stays fp32 for the attention backward)
         y, ln_y = self._resid_gemm(o_op, f'{pre}.{attn}.proj', x, dm, pre, nxt)
         if self.fold:      # backward needs xhat and rstd only: the fp32 sub-layer input is not kept
@@ -453,17 +491,19 @@ class Engine:
             sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, qkv=qkv, o=o, lse=lse, dm=dm) if need_grad else None
         if sv is not None and self.x3 and self.x3_planes and not self.recompute:
             sv['o_op'] = o_op
-        return y, sv, ln_y
+        return y, sv, ln_y, None
 
-    def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1, ln=None, nxt=None):
+    def _mlp_fwd(self, x, pre, norm, mlp, need_grad, sub=1, ln=None, nxt=None, pending_proj=None):
         cfg, ops, P = self.cfg, self.ops, self.P
         M, C = self.M, cfg.C
         if self.rawln:                # no-grad: the whole sub-layer is one kernel; the hidden never reaches HBM, the operand is bf16(x) made in the kernel
             lin = f'{pre}.{mlp}.fc1'
             y = self._f(M, C)
-            if isinstance(ln, dict):      # x + proj(o) first, in the same kernel
-                ops.proj_mlp_fused_fwd(ln['o'], self.Pk[f'{pre}.{mlp}'], P[ln['proj'] + '.bias'], self.Bf[lin], P[f'{pre}.{mlp}.fc2.bias'],
-                                       self.Rs[lin], x, y, cfg.eps)
+            if pending_proj is not None:      # x + proj(o) first, in the same kernel
+                if self.Pk_proj.get(f'{pre}.{mlp}') != pending_proj['proj']:
+                    raise RuntimeError(f"{pre}.{mlp}: packed with {self.Pk_proj.get(f'{pre}.{mlp}')} in front, asked to run {pending_proj['proj']}")
+                ops.proj_mlp_fused_fwd(pending_proj['o'], self.Pk[f'{pre}.{mlp}'], P[pending_proj['proj'] + '.bias'], self.Bf[lin],
+                                       P[f'{pre}.{mlp}.fc2.bias'], self.Rs[lin], x, y, cfg.eps)
             else:
                 ops.mlp_fused_fwd(None, True, self.Pk[f'{pre}.{mlp}'], self.Bf[lin], P[f'{pre}.{mlp}.fc2.bias'], self.Rs[lin], x, y, None,
                                   cfg.eps, None, None)

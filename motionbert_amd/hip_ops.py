@@ -127,6 +127,7 @@ class HipOps:
         self._ws_cache: Dict[tuple, int] = {}
         self._desc_cache: Dict[tuple, dict] = {}
         self._xcc_ok: Dict[int, bool] = {}
+        self.weight_cache: Dict[int, tuple] = {}      # device index -> (key, prepared weights) of the last no-grad forward (engine.prepare_weights)
         self._lock = threading.Lock()
 
     # ------------------------------------------------------------------ plumbing

@@ -265,8 +265,9 @@ class MockOps:
         self._log('rows_gemm.ln')
         mu = x.mean(-1, keepdim=True)
         rs = torch.rsqrt(((x - mu) ** 2).mean(-1, keepdim=True) + eps)
-        acc = x.to(packed.dtype).float() @ packed.float().t()
-        out_t.copy_((rs * (acc - mu * rsum) + bias).to(out_t.dtype))
+        sh = x[:, :1]                  # the kernel rounds the row SHIFTED by its first element (LayerNorm does not see the shift)
+        acc = (x - sh).to(packed.dtype).float() @ packed.float().t()
+        out_t.copy_((rs * (acc - (mu - sh) * rsum) + bias).to(out_t.dtype))
 
     def proj_mlp_pack_weights(self, wp_t, w1_t, w2_t):
         self._log('proj_mlp_pack_weights')
@@ -285,15 +286,16 @@ class MockOps:
     def mlp_fused_fwd(self, a_t, raw_in, packed, b1, b2, rsum, resid, y, y_t, eps, mean, rstd):
         """y = resid + fc2(gelu(fc1)), fc1 = a . W1^T + b1 (raw_in = 0: a is the normalised operand) or
         rstd_a (a . W1^T - mean_a rsum) + b1 with (mean_a, rstd_a) the statistics of the bf16 rows of a (raw_in = 1);
-        a_t = None: the operand is T(resid) and (mean_a, rstd_a) are the statistics of the fp32 rows of resid;
+        a_t = None: the operand is T(resid - resid[:, 0]) and (mean_a, rstd_a) are the statistics of the same shifted fp32 rows;
         the hidden passes through the operand type once (the kernel packs gelu(.) to bf16 for the second MFMA);
         y_t = T(y); mean / rstd = LayerNorm statistics of the rows of y."""
         self._log('mlp_fused_fwd' + ('' if a_t is not None else '.from_x'))
         w1_t, w2_t = packed
-        if a_t is None:           # the operand is T(resid); the statistics are those of the fp32 rows
-            a_t = resid.to(w1_t.dtype)
-            mu = resid.mean(-1, keepdim=True)
-            rs = torch.rsqrt(((resid - mu) ** 2).mean(-1, keepdim=True) + eps)
+        if a_t is None:           # the operand is T(resid - resid[:, 0]); the statistics are those of the fp32 rows (shifted alike)
+            sh = resid[:, :1]
+            a_t = (resid - sh).to(w1_t.dtype)
+            mu = resid.mean(-1, keepdim=True) - sh
+            rs = torch.rsqrt(((resid - sh - mu) ** 2).mean(-1, keepdim=True) + eps)
         elif raw_in:
             af = a_t.float()
             mu = af.mean(-1, keepdim=True)

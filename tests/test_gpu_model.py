@@ -682,3 +682,49 @@ def test_dropout_and_droppath_training_on_gpu(precision):
         assert not torch.equal(a, b)
         model.eval()
         assert rel_l2(model(x).cpu().numpy(), z['out']) < (TOL_FP32 if precision != 'bf16' else TOL_BF16_OUT)
+
+
+def test_no_grad_weight_cache_follows_the_parameters():
+    """The no-grad path keeps its prepared weights (folded / packed copies) between calls (engine.prepare_weights): a
+    second call launches no fold / pack kernels, an in-place parameter update is picked up, and a NEW model that the allocator
+    places at the old one's addresses (same version counters) does not hit the old entry."""
+    from motionbert_amd import engine, hip_ops
+    calls = []
+    orig = engine.Engine._prepare_weights
+
+    def counting(self, need_grad):
+        calls.append(need_grad)
+        return orig(self, need_grad)
+    engine.Engine._prepare_weights = counting
+    try:
+        hip_ops.get().weight_cache.clear()
+        x = make_input(2, 27, 17, 21).to(DEV)
+        model = build_model(FULL, seed=3)
+        trained_like(model, 3)
+        model = model.to(DEV).eval()
+        with torch.no_grad():
+            y0 = model(x)
+            y1 = model(x)
+            assert len(calls) == 1 and torch.equal(y0, y1)
+            model.blocks_st[2].mlp_t.fc1.weight.mul_(1.25)          # in place: the version counter moves
+            y2 = model(x)
+            assert len(calls) == 2 and not torch.equal(y2, y0)
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
+            del model
+            torch.cuda.synchronize()
+            other = build_model(FULL, seed=4)
+            trained_like(other, 4)
+            other = other.to(DEV).eval()      # very likely the same addresses and versions
+            y3 = other(x)
+            assert len(calls) == 3
+            other.load_state_dict(sd)
+            assert torch.equal(other(x), y2) and len(calls) == 4
+        # a training forward never uses (or fills) the cache
+        other.train()
+        other(x).sum().backward()
+        assert calls[-1] is True and len(calls) == 5
+        other.eval()
+        with torch.no_grad():
+            assert torch.equal(other(x), y2) and len(calls) == 5      # the entry of the last no-grad call is still valid: nothing changed
+    finally:
+        engine.Engine._prepare_weights = orig

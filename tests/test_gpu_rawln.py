@@ -153,3 +153,30 @@ def test_proj_mlp_fused(ops, M, C, hidden):
     xin = x.clone()
     ops.proj_mlp_fused_fwd(o, packed, bp, b1, b2, rsum, xin, xin, eps)
     assert torch.equal(xin, y)
+
+
+@pytest.mark.parametrize('offset', [0.0, 40.0, -300.0])
+@pytest.mark.parametrize('proj', [False, True])
+def test_fused_mlp_on_rows_with_a_large_common_offset(ops, offset, proj):
+    """The fused MLP (operand made in the kernel from the fp32 rows; with `proj` from the accumulators holding x + o.Wp^T + bp) against
+    the EXACT sub-layer in fp64 on rows whose mean is up to 600x their spread: the operand is the row shifted by its first
+    element, so the LayerNorm's cancellation happens before the bf16 rounding, not after it."""
+    M, C, hidden, eps = 4131, 512, 1024, 1e-6
+    x = rnd(M, C, seed=21) * 0.5 + offset
+    w1, w2 = rnd(hidden, C, seed=22, dtype=BF, scale=0.06), rnd(C, hidden, seed=23, dtype=BF, scale=0.04)
+    b1, b2 = rnd(hidden, seed=24, scale=0.3), rnd(C, seed=25, scale=0.3)
+    rsum = w1.float().sum(1)
+    y = torch.full((M, C), float('nan'), device=DEV)
+    xd = x.double()
+    if proj:
+        o, wp, bp = rnd(M, C, seed=26, dtype=BF), rnd(C, C, seed=27, dtype=BF, scale=0.02), rnd(C, seed=28, scale=0.3)
+        ops.proj_mlp_fused_fwd(o, ops.proj_mlp_pack_weights(wp, w1, w2), bp, b1, b2, rsum, x, y, eps)
+        xd = xd + o.double() @ wp.double().t() + bp.double()
+    else:
+        ops.mlp_fused_fwd(None, True, ops.mlp_pack_weights(w1, w2), b1, b2, rsum, x, y, None, eps, None, None)
+    mu = xd.mean(-1, keepdim=True)
+    xhat = (xd - mu) * torch.rsqrt(((xd - mu) ** 2).mean(-1, keepdim=True) + eps)
+    branch = torch.nn.functional.gelu(xhat @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    got = y.double() - xd                 # (fp32 y = x + branch: at |x| ~ 300 the sum itself is only good to 2^-24 * 300 = 2e-5)
+    err = float((got - branch).norm() / branch.norm())
+    assert err < 1.2e-2, f'offset {offset} proj {proj}: branch error {err:.2e} against the exact sub-layer'

@@ -89,11 +89,32 @@ def test_rows_gemm_from_the_fp32_rows(ops, M, N, K):
     mu = xd.mean(-1)
     rs = torch.rsqrt(((xd - mu[:, None]) ** 2).mean(-1) + eps)
     two = torch.empty_like(out)
-    ops.rows_gemm_nk(x.to(BF), packed, bias, two, rsum, mu.float(), rs.float())
+    # (the kernel's operand is the row shifted by its first element, the statistics are those of the shifted row)
+    ops.rows_gemm_nk((x - x[:, :1]).to(BF), packed, bias, two, rsum, (mu - xd[:, 0]).float(), rs.float())
     d = (out.float() - two.float()).abs()
     ulp = two.float().abs().clamp_min(2.0 ** -6) * 2.0 ** -7      # one bf16 step at the value's magnitude
     assert float((d / ulp).max()) <= 2.0, f'in-kernel LayerNorm statistics: {float((d / ulp).max()):.2f} bf16 steps'
     assert float((d > 0).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize('offset', [0.0, 40.0, -300.0])
+def test_rows_gemm_from_rows_with_a_large_common_offset(ops, offset):
+    """Against the EXACT Linear(LayerNorm(x)) (fp64 statistics and normalisation, the bf16 weights) on rows whose mean is up to 600x
+    their spread -- what a trained residual stream may carry.  The kernel rounds the row shifted by its first element, so
+    the error stays at the bf16 level of the normalised operand whatever the offset; rounding the raw row would lose
+    sqrt(1 + mean^2 / var) of it (0.25 / 1.9 relative L2 at these offsets instead of ~3e-3)."""
+    M, N, K, eps = 4131, 1536, 512, 1e-6
+    x = rnd(M, K, seed=11) * 0.5 + offset
+    w = rnd(N, K, seed=12, dtype=BF, scale=0.05)
+    bias = rnd(N, seed=13, scale=0.5)
+    out = torch.full((M, N), float('nan'), device=DEV, dtype=BF)
+    ops.rows_gemm_nk_ln(x, ops.rows_pack_nk(w), bias, w.float().sum(1), eps, out)
+    xd = x.double()
+    mu = xd.mean(-1, keepdim=True)
+    xhat = (xd - mu) * torch.rsqrt(((xd - mu) ** 2).mean(-1, keepdim=True) + eps)
+    exact = xhat @ w.double().t() + bias.double()
+    err = float((out.double() - exact).norm() / exact.norm())
+    assert err < 8e-3, f'offset {offset}: {err:.2e} against the exact LayerNorm + Linear'
 
 
 def test_rows_gemm_rejects_bad_shapes(ops):
