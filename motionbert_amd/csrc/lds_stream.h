@@ -17,6 +17,14 @@ __device__ __forceinline__ void glds16(const void* src, const void* lds_dst) {
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 #define GLDS16(src, dst) glds16((src), (dst))
+// the same with the non-temporal policy: for one-touch activation rows, so that they do not push the weight stream (which every CU of
+// the XCD re-reads) out of the 4 MiB L2
+__device__ __forceinline__ void glds16_nt(const void* src, const void* lds_dst) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(uintptr_t)(const lds_void_t*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
 // The weight stream's form: wave-uniform 64-bit base in SGPRs + this lane's constant 32-bit byte offset in a VGPR (no per-piece
 // vector address arithmetic), M0 written but not restored -- nothing the compiler emits in this kernel reads M0 (gfx9+ LDS
 // instructions do not), and every DMA statement sets it itself.

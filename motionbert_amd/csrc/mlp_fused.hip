@@ -48,6 +48,13 @@
 #ifndef MBX_MLP_DBG
 #define MBX_MLP_DBG 0
 #endif
+// A/B: cache policy of the tile's one-touch activation traffic.  bit 0: non-temporal stores of y in the epilogue; bit 1: non-temporal
+// LDS-DMA loads of o and the residual rows in the prologue.  (The weight stream, 2.5 MiB that all 32 CUs of an XCD re-read every
+// tile, competes with ~20 MiB of activations per tile period for the 4 MiB L2.)
+#ifndef MBX_MLP_NT
+#define MBX_MLP_NT 0
+#endif
+#define MF_GLDS_ACT(src_, dst_) do { if (MBX_MLP_NT & 2) glds16_nt((src_), (dst_)); else GLDS16((src_), (dst_)); } while (0)
 static constexpr int F_BM = 128;               // token rows per workgroup (4 waves x 32)
 static constexpr int F_STAGE = 32 * 1024;      // one ring stage = 32 fragments of 1 KiB
 static constexpr int F_RING = 4 * F_STAGE;     // 128 KiB
@@ -110,14 +117,21 @@ __device__ __forceinline__ float2 ge_bias_ld(const char* p) {
 // (the accumulator layout holds columns 8 q + 4 g + e of a token, an operand fragment 8 consecutive ones: one v_permlane32_swap
 // per register pair) and takes the LayerNorm statistics of y1 from the same values.  y1 never exists in HBM (- 8 bytes per element),
 // one launch less per Block half.
-// Diagnostic builds only (tools/build_variants.py name -DMBX_MLP_TRACE; tools/mlp_trace.py): 16 time stamps per workgroup (wave 0),
-// s_memrealtime ticks (100 MHz) in slots 0..14, the shader-cycle counter at entry / exit in the upper halves of slots 0 / 14, the
-// hardware id in slot 15.  The buffer address comes from the environment variable MBX_TRACE_BUF of the host process.
+// Diagnostic builds only (tools/build_variants.py name -DMBX_MLP_TRACE; tools/mlp_trace.py): 24 int64 per workgroup (wave 0):
+// s_memrealtime ticks (100 MHz) in slots 0..14 (phases) and 16..20 (the four stages of chunk 8), the hardware id in slot 15, the
+// shader-cycle counter at entry / exit in slots 22 / 23.  The buffer address comes from the environment variable MBX_TRACE_BUF.
 #ifdef MBX_MLP_TRACE
 __device__ long long* g_mlp_trace;
 #define MF_TS(slot_) do { if (tr_on) tr[slot_] = (long long)wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// (the stage stamps inside the chunk loop stay in scalar registers and are written out at the end: nothing for the loop to carry in VGPRs)
+#if MBX_MLP_TRACE + 0 >= 2      // (a second trace build: these five stamps cost the register allocator 20 bytes of scratch in the PROJ form)
+#define MF_TSC(slot_) do { if (c == 8) tsc[(slot_) - 16] = (long long)wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MF_TSC(slot_) do { } while (0)
+#endif
 #else
 #define MF_TS(slot_) do { } while (0)
+#define MF_TSC(slot_) do { } while (0)
 #endif
 
 template <int C, bool PROJ = false>
@@ -153,9 +167,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     float* const bps = reinterpret_cast<float*>(smem + F_RING + (size_t)(2 * hidden + C) * 4 + (C == 512 ? 4 * 4096 : 0));   // PROJ: bp [C] behind everything else
 #ifdef MBX_MLP_TRACE
     const bool tr_on = g_mlp_trace != nullptr && tid == 0;
-    long long* const tr = g_mlp_trace + (size_t)blockIdx.x * 16;
-    if (tr_on) { tr[15] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); tr[16 * gridDim.x + blockIdx.x] = (long long)__builtin_readcyclecounter(); }
+    long long* const tr = g_mlp_trace + (size_t)blockIdx.x * 24;
+    if (tr_on) { tr[15] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); tr[22] = (long long)__builtin_readcyclecounter(); }
 #endif
+    long long tsc[5] = {0, 0, 0, 0, 0};
     MF_TS(0);
 
     // (Measured and dropped, round 4: a start stagger of the first workgroup of every CU by k/8 of a tile period, to run the memory
@@ -174,6 +189,121 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     const bool from_x = xh == nullptr;             // wave-uniform (a kernel argument)
     u32x4_t X[KS];
     float ln_rs = 1.f, ln_k = 0.f;
+    f32x16_t acc2[NT2];
+    float xsh = 0.f, xs1 = 0.f, xs2 = 0.f;         // from_x: shifted sums over this lane's half row
+#ifndef MBX_MLP_PRO_PIPE
+#define MBX_MLP_PRO_PIPE 1
+#endif
+#if MBX_MLP_PRO_PIPE
+    // ---- (round 5) the tile's inputs arrive as a PIPELINE of 16-KiB jobs through two buffers (the halves of the wave's 32 KiB of the
+    // ring, which is idle until the weight stream starts): o in column halves (-> X fragments), then the residual rows in quarters of
+    // 128 columns (-> four accumulator tiles each, which START from residual + bias so that the epilogue only writes; from_x: also
+    // the operand fragments and the row statistics).  Job k + 2 is requested as soon as job k has been read out of its buffer, so one
+    // or two jobs (64-128 KiB per CU) are in flight while the lanes move the previous one into registers.  Round 4 ran three 32-KiB
+    // phases strictly one after the other -- request, drain, read: 17.9 us per tile in situ (profiles/r05_mlp_trace_before.txt).
+    //   o job h:        instruction jj = 8 rows x 128 B: row group rb = jj & 3, column segment 4 h + (jj >> 2); image as in round 4
+    //   residual job q: instruction r2 = rows 2 r2, 2 r2 + 1 x 512 B (columns [128 q, 128 q + 128)); 16-byte piece p of row r at slot
+    //                   p ^ (r & 15) (applied to the source address): conflict-free in the accumulator layout -- lane (i, g): row i,
+    //                   piece 8 ntl + 2 qq + g -- and in the operand-fragment layout -- row i, pieces 4 sl + 2 g, + 1.
+    {
+        constexpr int NO = KS / 16, NQ = C / 128;  // o jobs (xh given), residual jobs
+        char* const bufA = ring + wave * 32768;
+        char* const bufB = bufA + 16384;
+        const int xr = lane >> 3, xp = lane & 7;
+        auto issue_o = [&](int h, char* buf) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int rb = jj & 3, cs = 4 * h + (jj >> 2);
+                const int row = min(mw + 8 * rb + xr, M - 1);
+                MF_GLDS_ACT(xh + (size_t)row * C + cs * 64 + ((xp ^ x_swz(xr, rb)) << 3), buf + jj * 1024);
+            }
+        };
+        auto issue_q = [&](int q, char* buf) {
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                const int rl = 2 * r2 + (lane >> 5), p = lane & 31;
+                MF_GLDS_ACT(resid + (size_t)min(mw + rl, M - 1) * C + q * 128 + ((p ^ (rl & 15)) << 2), buf + r2 * 1024);
+            }
+        };
+        auto read_o = [&](int h, const char* buf) {
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) {
+                const int rb = i >> 3, r = i & 7, p = 2 * (sl & 3) + g;
+                X[16 * h + sl] = *reinterpret_cast<const u32x4_t*>(buf + ((sl >> 2) * 4 + rb) * 1024 + r * 128 + ((p ^ x_swz(r, rb)) << 4));
+            }
+        };
+        auto read_q = [&](int q, const char* buf) {
+#pragma unroll
+            for (int ntl = 0; ntl < 4; ++ntl) {
+                const int nt = 4 * q + ntl;
+                f32x16_t t;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 bb = *reinterpret_cast<const float4*>((PROJ ? bps : b2s) + nt * 32 + 8 * qq + 4 * g);   // (PROJ: bp + b2)
+                    const float4 xv = *reinterpret_cast<const float4*>(buf + i * 512 + (((ntl * 8 + 2 * qq + g) ^ (i & 15)) << 4));
+                    t[4 * qq] = xv.x + bb.x; t[4 * qq + 1] = xv.y + bb.y; t[4 * qq + 2] = xv.z + bb.z; t[4 * qq + 3] = xv.w + bb.w;
+                    if (from_x) {
+                        if (q == 0 && ntl == 0 && qq == 0) xsh = wave_lower_half(xv.x);      // x[row][0] for both half rows (see below)
+                        const float d0 = xv.x - xsh, d1 = xv.y - xsh, d2 = xv.z - xsh, d3 = xv.w - xsh;
+                        xs1 += (d0 + d1) + (d2 + d3);
+                        xs2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, xs2))));
+                    }
+                }
+                acc2[nt] = t;
+                asm volatile("s_nop 1" : "+a"(acc2[nt]));             // a whole tile at a time into accumulator registers, where it stays
+            }
+            if (from_x) {
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {                      // k-steps 8 q + sl: eight consecutive channels of row i per lane
+                    const float4 lo = *reinterpret_cast<const float4*>(buf + i * 512 + (((4 * sl + 2 * g) ^ (i & 15)) << 4));
+                    const float4 hi = *reinterpret_cast<const float4*>(buf + i * 512 + (((4 * sl + 2 * g + 1) ^ (i & 15)) << 4));
+                    // operand = bf16(x - x[row][0]): LayerNorm does not see the shift, and the rounding error then scales with the spread
+                    // of the row, not with its magnitude (gemm_rows.hip, FROMX)
+                    X[8 * q + sl] = u32x4_t{pack_bf2(lo.x - xsh, lo.y - xsh), pack_bf2(lo.z - xsh, lo.w - xsh), pack_bf2(hi.x - xsh, hi.y - xsh),
+                                            pack_bf2(hi.z - xsh, hi.w - xsh)};
+                }
+            }
+        };
+        // job list: [o 0 .. NO - 1 (xh given)] + [residual 0 .. NQ - 1]; job k lives in buffer k & 1
+#define MF_PRO_ISSUE(k_, no_) do { if ((k_) < (no_)) issue_o((k_), ((k_) & 1) ? bufB : bufA); else issue_q((k_) - (no_), ((k_) & 1) ? bufB : bufA); } while (0)
+#define MF_PRO_JOBS(no_)                                                                                             \
+        do {                                                                                                         \
+            constexpr int NJ_ = (no_) + NQ;                                                                          \
+            MF_PRO_ISSUE(0, no_);                                                                                    \
+            MF_PRO_ISSUE(1, no_);                                                                                    \
+            _Pragma("unroll") for (int k_ = 0; k_ < NJ_; ++k_) {                                                     \
+                if (k_ + 1 < NJ_) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                  \
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+                if (k_ == (no_)) {        /* the first residual job reads the biases: they are in LDS behind this barrier */ \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+                    __builtin_amdgcn_s_barrier();                                                                    \
+                }                                                                                                    \
+                if (k_ < (no_)) read_o(k_, (k_ & 1) ? bufB : bufA); else read_q(k_ - (no_), (k_ & 1) ? bufB : bufA); \
+                if (k_ + 2 < NJ_) {                                                                                  \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* the buffer has been read out */      \
+                    MF_PRO_ISSUE(k_ + 2, no_);                                                                       \
+                }                                                                                                    \
+            }                                                                                                        \
+        } while (0)
+        if (!from_x) MF_PRO_JOBS(NO);
+        else MF_PRO_JOBS(0);
+        MF_TS(4);
+        if (!from_x && raw_in && !PROJ) {          // wave-uniform (PROJ: the operand of fc1 and its statistics come from the proj product)
+            float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                sa = dot2_bf16(X[s][0], 0x3f803f80u, sa); qa = dot2_bf16(X[s][0], X[s][0], qa);
+                sb = dot2_bf16(X[s][1], 0x3f803f80u, sb); qb = dot2_bf16(X[s][1], X[s][1], qb);
+                sa = dot2_bf16(X[s][2], 0x3f803f80u, sa); qa = dot2_bf16(X[s][2], X[s][2], qa);
+                sb = dot2_bf16(X[s][3], 0x3f803f80u, sb); qb = dot2_bf16(X[s][3], X[s][3], qb);
+            }
+            const float st = wave_halves<WaveAdd>(sa + sb), qt = wave_halves<WaveAdd>(qa + qb);
+            const float mu = st * (1.0f / (float)C);
+            ln_rs = 1.0f / sqrtf(fmaxf(qt * (1.0f / (float)C) - mu * mu, 0.f) + eps);
+            ln_k = -ln_rs * mu;
+        }
+    }
+#else
     if (!from_x) {
         // the wave's 32 rows of xh -> LDS (wave-private image, whole 128-byte lines per DMA) -> operand fragments
         char* const ximg = ring + wave * (64 * C);
@@ -182,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
         for (int j = 0; j < KS; ++j) {             // one instruction = 8 rows x 128 B: row group rb = j & 3, column segment j >> 2
             const int rb = j & 3, cs = j >> 2;
             const int row = min(mw + 8 * rb + xr, M - 1);
-            GLDS16(xh + (size_t)row * C + cs * 64 + ((xp ^ x_swz(xr, rb)) << 3), ximg + j * 1024);
+            MF_GLDS_ACT(xh + (size_t)row * C + cs * 64 + ((xp ^ x_swz(xr, rb)) << 3), ximg + j * 1024);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -215,15 +345,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     // KiB; 16-byte piece p of row r at p ^ (r & 15), applied to the source address: conflict-free in the accumulator layout -- lane
     // (i, g): row i, piece 8 ntl + 2 qq + g --, in the operand-fragment layout -- row i, pieces 4 s + 2 g, + 1 -- and row-major), and
     // each lane takes its accumulator registers from it; from_x: also its operand fragments and its half of the row's statistics.
-    f32x16_t acc2[NT2];
     char* const er = ring + wave * 32768;
-    float xsh = 0.f, xs1 = 0.f, xs2 = 0.f;         // from_x: shifted sums over this lane's half row
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the image's previous readers (X fragments / first half) are done
 #pragma unroll 4
         for (int r = 0; r < 32; ++r)
-            GLDS16(resid + (size_t)min(mw + r, M - 1) * C + hh * 256 + ((lane ^ (r & 15)) << 2), er + r * 1024);
+            MF_GLDS_ACT(resid + (size_t)min(mw + r, M - 1) * C + hh * 256 + ((lane ^ (r & 15)) << 2), er + r * 1024);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ntl = 0; ntl < 8; ++ntl) {
@@ -257,6 +385,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             }
         }
     }
+#endif
     if (from_x) {                                  // the row statistics: this lane's half and the partner lane's (lane ^ 32), Chan's formula
         constexpr float nh = (float)(C / 2);
         const float mean_h = xsh + xs1 / nh, m2_h = xs2 - xs1 * xs1 / nh;
@@ -359,8 +488,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
 // GELU over all four stages of a chunk buy?)
 #define GE_SRC(j_, tn_, r_) (((MBX_MLP_DBG & 128) && (j_) < 8) ? ge_dummy : acc1[tn_][r_])
     float ge_dummy = ln_rs;
+// (scalar since round 5: measured 1-2 % faster than the packed form in two sessions -- packed fp32 VALU beside MFMAs costs more than its
+// two scalar halves, MI355X_MICROARCH.md "price of one filler beside MFMAs"; MBX_MLP_GELU_SCALAR=0 is the A/B switch)
 #ifndef MBX_MLP_GELU_SCALAR
-#define MBX_MLP_GELU_SCALAR 0
+#define MBX_MLP_GELU_SCALAR 1
 #endif
 #if MBX_MLP_GELU_SCALAR      // A/B form: the same arithmetic on scalar fp32 operations (two interleaved chains, no packed instructions)
     float gu0, gu1, ga0, ga1, gd0, gd1;
@@ -434,8 +565,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     } while (0)
 
     if constexpr (PROJ) {
-        // ---- proj: acc2 (= resid + bp) += o . Wp^T.  One stage = 32 / NT2 k-steps x NT2 output tiles; the token fragments of the
-        // stage's k-steps are copied out of X into fixed registers first (X cannot be indexed by the stage counter).
+        // ---- proj: acc2 (= resid + bp) += o . Wp^T.  One stage = 32 / NT2 k-steps x NT2 output tiles.
+#ifndef MBX_MLP_PROJ_UNROLL
+#define MBX_MLP_PROJ_UNROLL 1
+#endif
+#if MBX_MLP_PROJ_UNROLL
+        // (round 5) every stage written out: the token fragments are then named registers.  The rolled loop of round 4 had to pick
+        // them out of X by a chain of compares per stage (X cannot be indexed by a run-time stage counter) and paid a taken branch
+        // between two MFMA bursts: 1.47 us per stage in situ where the weight stream allows 0.6 (profiles/r05_mlp_trace_before.txt).
+#define MMA_P(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, X[KKS * p + (k_) / NT2])
+#pragma unroll
+        for (int p = 0; p < NPS; ++p) MF_STAGE(MMA_P, HOOK_NONE);
+#else
         u32x4_t xk[KKS];
 #define MMA_P(k_, w_) MFMA_FC2(acc2[(k_) % NT2], w_, xk[(k_) / NT2])
         for (int p = 0; p < NPS; ++p) {
@@ -447,6 +588,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                 }
             MF_STAGE(MMA_P, HOOK_NONE);
         }
+#endif
         MF_TS(7);
         // ---- y1 sits in the accumulators: operand fragments and LayerNorm statistics from them.  Lane (i, g) holds columns
         // 32 nt + 8 q + 4 g + e of token i in acc2[nt][4 q + e]; fragment s = 2 nt + h wants its columns 16 s + 8 g + [0, 8): quads
@@ -477,11 +619,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
             for (int h = 0; h < 2; ++h) {
                 float a[4], b[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[e] = t[8 * h + e];
-                    b[e] = t[8 * h + 4 + e];
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[e]), "+v"(b[e]));
-                }
+                for (int e = 0; e < 4; ++e) { a[e] = t[8 * h + e]; b[e] = t[8 * h + 4 + e]; }
+                // four swaps behind ONE hazard pad (the VALU writes above -> permlane read; swap -> swap of other registers needs none)
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7"
+                             : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]));
                 X[2 * nt + h] = u32x4_t{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
                 asm volatile("" : "+v"(X[2 * nt + h]));      // packed HERE (otherwise the conversions sink to the fragment's first use and the floats spill)
             }
@@ -514,11 +655,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     G_ROTATE();
     MF_TS(9);
     for (int c = 1; c < nch; ++c) {
-        MF_PART_A();                       // A(c)
+        MF_TSC(16);                        // (trace builds: the four stages of chunk 8, stamped one by one)
+        MF_STAGE(MMA_A0, HOOK_PA0);        // A(c)
+        MF_TSC(17);
+        if constexpr (S2 == 2) MF_STAGE(MMA_A1, HOOK_PA1);
+        MF_TSC(18);
         gc = c;
         GE_LOAD(0);
         MF_STAGE(MMA_B0, HOOK_G0);         // B(c - 1) || gelu(c)
+        MF_TSC(19);
         if constexpr (S2 == 2) MF_STAGE(MMA_B1, HOOK_G1);
+        MF_TSC(20);
         G_ROTATE();
     }
     MF_TS(10);
@@ -570,7 +717,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
 #pragma unroll 4
         for (int r = 0; r < rows; ++r) {
             const float4 t = *reinterpret_cast<const float4*>(eo + r * 1024 + ((lane_e ^ (r & 15)) << 4));
-            *reinterpret_cast<float4*>(yrow + (size_t)r * C + lane_e * 4) = t;
+            if (MBX_MLP_NT & 1) {
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(nt_f4{t.x, t.y, t.z, t.w}, reinterpret_cast<nt_f4*>(yrow + (size_t)r * C + lane_e * 4));
+            } else {
+                *reinterpret_cast<float4*>(yrow + (size_t)r * C + lane_e * 4) = t;
+            }
             if (yb_out != nullptr)
                 *reinterpret_cast<uint2*>(brow + (size_t)r * C + lane_e * 4) = make_uint2(pack_bf2(t.x, t.y), pack_bf2(t.z, t.w));
         }
@@ -579,7 +731,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     MF_TS(13);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MF_TS(14);
-    if (tr_on) tr[16 * gridDim.x + gridDim.x + blockIdx.x] = (long long)__builtin_readcyclecounter();
+    if (tr_on) { tr[23] = (long long)__builtin_readcyclecounter(); tr[16] = tsc[0]; tr[17] = tsc[1]; tr[18] = tsc[2]; tr[19] = tsc[3]; tr[20] = tsc[4]; }
 #endif
     if (want_stats) {
         constexpr float nh = (float)(C / 2);                          // values per lane

@@ -23,7 +23,7 @@ for step in "$@"; do
   n=$((n + 1)); kind=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}
   echo "== [$TAG] $step"
   case $kind in
-    env) export "$arg" ;;
+    env) export "$(sp "$arg")" ;;
     pytest) timeout 1700 python -m pytest tests -q -m gpu -p no:cacheprovider ${arg:+-k "$(sp "$arg")"} 2>&1 | out pytest$n 8 300 ;;
     file) f=${arg%%:*}; k=""; [[ "$arg" == *:* ]] && k=${arg#*:}; timeout 1700 python -m pytest "$f" -q -p no:cacheprovider -x ${k:+-k "$(sp "$k")"} 2>&1 | out file$n 8 300 ;;
     bench) timeout 900 python bench.py $(sp "${arg:---no-cpu-baseline}") 2>gpurun_out/${TAG}_bench$n.log | out bench$n 2 4000 ;;

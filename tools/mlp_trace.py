@@ -1,5 +1,5 @@
 """Diagnostics (-DMBX_MLP_TRACE build): where a 128-row tile of the fused proj + MLP kernel spends its time IN SITU -- 15 time stamps
-per workgroup (s_memrealtime, 10 ns ticks), all workgroups of one launch.
+per workgroup (s_memrealtime, 10 ns ticks), all workgroups of one launch (-DMBX_MLP_TRACE=2: also the four stages of one chunk).
     python tools/build_variants.py mlptrace -DMBX_MLP_TRACE
     MBX_LIB=tools/variants/libmbx_mlptrace.so python tools/mlp_trace.py [clips] [proj=1]"""
 import os
@@ -14,7 +14,7 @@ clips = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 proj = (sys.argv[2] if len(sys.argv) > 2 else '1') == '1'
 C, hidden, M, dev, BF = 512, 1024, clips * 243 * 17, 'cuda', torch.bfloat16
 tiles = (M + 127) // 128
-buf = torch.zeros(18 * tiles + 64, dtype=torch.int64, device=dev)
+buf = torch.zeros(24 * tiles + 64, dtype=torch.int64, device=dev)
 os.environ['MBX_TRACE_BUF'] = hex(buf.data_ptr())
 from motionbert_amd import hip_ops   # noqa: E402
 
@@ -43,10 +43,13 @@ fn()
 e1.record()
 torch.cuda.synchronize()
 t = buf.cpu().numpy()
-st = t[:16 * tiles].reshape(tiles, 16).astype(np.float64)
-cyc0, cyc1 = t[16 * tiles:17 * tiles].astype(np.float64), t[17 * tiles:18 * tiles].astype(np.float64)
+raw = t[:24 * tiles].reshape(tiles, 24)
+st = raw[:, :16].astype(np.float64)
+cyc0, cyc1 = raw[:, 22].astype(np.float64), raw[:, 23].astype(np.float64)
 if not proj:
     st[:, 7] = st[:, 6]
+for k in (1, 2, 3):      # the pipelined prologue (round 5) is one phase: stamps 1..3 are not written
+    st[:, k] = np.where(st[:, k] == 0, st[:, k - 1], st[:, k])
 t0 = st[:, 0].min()
 us = (st[:, :15] - t0) / 100.0          # 100 MHz ticks -> us since the first workgroup's entry
 names = ['o -> X fragments (DMA + wait + reads)', 'barrier', 'residual half 0 -> acc2', 'residual half 1 -> acc2', 'fp32 -> operand / barrier',
@@ -75,5 +78,8 @@ grid = np.linspace(0, us[:, 14].max(), 2000)
 inpro = ((us[:, 0][None, :] <= grid[:, None]) & (grid[:, None] < us[:, 5][None, :])).sum(1)
 inepi = ((us[:, 12][None, :] <= grid[:, None]) & (grid[:, None] < us[:, 14][None, :])).sum(1)
 print(f'# workgroups inside the load phases at a time: mean {inpro.mean():.1f}, max {inpro.max()}; inside the store phase: mean {inepi.mean():.1f}, max {inepi.max()} (of 256 resident)')
-xcc = (t[:16 * tiles].reshape(tiles, 16)[:, 15] >> 32) & 0xf
+if raw[:, 16].min() > 0:      # -DMBX_MLP_TRACE=2: the four stages of chunk 8
+    sd = np.diff(raw[:, 16:21].astype(np.float64), axis=1) / 100.0
+    print('# chunk 8, median us per stage: ' + '  '.join(f'{n} {np.median(sd[:, k]):.2f}' for k, n in enumerate(('A0 (fc1)', 'A1 (fc1)', 'B0 (fc2 + GELU)', 'B1 (fc2 + GELU)'))))
+xcc = (raw[:, 15] >> 32) & 0xf
 print('# median tile time by XCC: ' + ' '.join(f'{int(c)}:{np.median(total[xcc == c]):.1f}' for c in np.unique(xcc)))
