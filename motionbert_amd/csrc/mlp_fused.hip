@@ -436,35 +436,55 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
     u32x4_t xl[XL > 0 ? XL : 1];                                // the LDS-resident fragments of X, in registers during the second fc1 stage only
     const unsigned fr = (unsigned)(uintptr_t)(const lds_void_t*)ring + lane * 16;   // fragment f of ring slot s: fr + s * F_STAGE + f * 1024
 
+    // Ring schedule (round 5, MBX_MLP_RING_DEEP = 1): the barrier of stage q sits in front of slot 32 - PF = 27 -- the first slot that reads
+    // a fragment of stage q + 1, and the first at which EVERY wave has issued its last read of stage q's buffer (slot 26) -- so that
+    // buffer is refilled right away with stage q + 4 (pieces 0, 1 in slots 27 and 31, pieces 2..7 in slots 3..23 of the next stage):
+    // three stages (96 KiB) of the stream are in flight and the last-issued piece of a stage has two stage times to land.  Round 4 put
+    // the barrier at slot 24 and refilled the buffer of stage q - 1 there, which had been idle for 29 slots by then: one and a half
+    // stages in flight, ONE stage time for the last piece -- and a stage took as long as that piece's latency (0.76 us in situ for
+    // 32 MFMAs = 0.5 us, with or without the GELU beside them: profiles/r05_mlp_trace_stages.txt).
+#ifndef MBX_MLP_RING_DEEP
+#define MBX_MLP_RING_DEEP 1
+#endif
+    constexpr int RD = MBX_MLP_RING_DEEP ? 1 : 0;               // extra stages of run-ahead
+    constexpr int SYNC_SLOT = RD ? 32 - PF : 24;
     int q = 0;                                                  // stage sequence number
     {
         const char* const s0 = wpk + seq_off(0);
         const char* const s1 = wpk + seq_off(1);
         const char* const s2 = wpk + seq_off(2);
+        const char* const s3 = wpk + seq_off(3);
 #pragma unroll
         for (int d = 0; d < 8; ++d) MF_ISSUE1(s0, 0, d);
 #pragma unroll
         for (int d = 0; d < 8; ++d) MF_ISSUE1(s1, 1, d);
-        MF_ISSUE1(s2, 2, 0);
-        MF_ISSUE1(s2, 2, 1);
+        if (RD) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) MF_ISSUE1(s2, 2, d);
+            MF_ISSUE1(s3, 3, 0);
+            MF_ISSUE1(s3, 3, 1);
+        } else {
+            MF_ISSUE1(s2, 2, 0);
+            MF_ISSUE1(s2, 2, 1);
+        }
     }
-    MF_SYNC(10);                                                // stage 0 is in LDS
+    if (RD) MF_SYNC(18); else MF_SYNC(10);                      // stage 0 is in LDS (younger: stages 1 [, 2] and two pieces)
     MF_TS(6);
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
 
     // One stage = 32 slots.  Slot k: read the fragment of slot k + PF (from slot 32 - PF on, a fragment of the NEXT stage: the
-    // barrier sits in front of slot 24), one MFMA, every fourth slot one LDS-DMA piece (slots 3..23: pieces 2..7 of stage q + 2,
-    // slots 27, 31: pieces 0, 1 of stage q + 3), then HOOK_ (GELU micro-steps); sched_barrier(0) pins the slot.
+    // barrier sits in front of that slot), one MFMA, every fourth slot one LDS-DMA piece (slots 3..23: pieces 2..7 of stage q + 3,
+    // slots 27, 31: pieces 0, 1 of stage q + 4), then HOOK_ (GELU micro-steps); sched_barrier(0) pins the slot.
 #define MF_STAGE(MMA_, HOOK_)                                                                                        \
     if (!(MBX_MLP_DBG & 64)) do {                                                                                    \
         unsigned st_ = fr + (q & 3) * F_STAGE, sn_ = fr + ((q + 1) & 3) * F_STAGE;                                   \
         asm volatile("" : "+v"(st_), "+v"(sn_));                                                                     \
-        const char* const n2_ = wpk + seq_off(q + 2);                                                                \
-        const char* const n3_ = wpk + seq_off(q + 3);                                                                \
-        const int l2_ = (q + 2) & 3, l3_ = (q + 3) & 3;                                                              \
+        const char* const n2_ = wpk + seq_off(q + 2 + RD);                                                           \
+        const char* const n3_ = wpk + seq_off(q + 3 + RD);                                                           \
+        const int l2_ = (q + 2 + RD) & 3, l3_ = (q + 3 + RD) & 3;                                                    \
         _Pragma("unroll") for (int k_ = 0; k_ < 32; ++k_) {                                                          \
-            if (k_ == 24 && !(MBX_MLP_DBG & 32)) MF_SYNC(8);                                                         \
+            if (k_ == SYNC_SLOT && !(MBX_MLP_DBG & 32)) { if (RD) MF_SYNC(16); else MF_SYNC(8); }                    \
             if (!(MBX_MLP_DBG & 4))                                                                                  \
                 fb[(k_ + PF) & 7] = k_ + PF < 32 ? lds_read16(st_, (k_ + PF) * 1024) : lds_read16(sn_, (k_ + PF - 32) * 1024); \
             if (!(MBX_MLP_DBG & 16) || (k_ & 15) == 0) MMA_(k_, fb[k_ & 7]);                                         \
@@ -654,6 +674,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restr
                         asm volatile("s_nop 3" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3])); } while (0)
     G_ROTATE();
     MF_TS(9);
+#ifdef MBX_MLP_ALIGN_PAD      // A/B: shift the chunk loop's code by 4 bytes (MI355X_MICROARCH.md: hand-placed streams can be sensitive to their 8-byte phase)
+    asm volatile("s_nop 0");
+#endif
     for (int c = 1; c < nch; ++c) {
         MF_TSC(16);                        // (trace builds: the four stages of chunk 8, stamped one by one)
         MF_STAGE(MMA_A0, HOOK_PA0);        // A(c)
