@@ -124,7 +124,8 @@ def test_gemm_nt_rawln(ops, M, N, K):
     check(f'gemm_nt_rawln.vs_layernorm.{M}x{N}x{K}', out, exact, 1e-2)
 
 
-@pytest.mark.parametrize('M,C,hidden', [(1000, 512, 1024), (128 * 3 + 5, 256, 1024), (4131, 512, 1024), (77, 512, 128), (2 * 243 * 17, 256, 1024)])
+@pytest.mark.parametrize('M,C,hidden', [(1000, 512, 1024), (128 * 3 + 5, 256, 1024), (4131, 512, 1024), (77, 512, 128), (2 * 243 * 17, 256, 1024),
+                                        (70227, 512, 1024), (33000, 256, 1024)])
 def test_proj_mlp_fused(ops, M, C, hidden):
     """mbx_proj_mlp_fused_fwd: attention proj + residual + LayerNorm + fc1 + GELU + fc2 + residual in one kernel, against the torch
     restatement (the proj product in fp32, then the fused-MLP restatement on it)."""
@@ -180,3 +181,24 @@ def test_fused_mlp_on_rows_with_a_large_common_offset(ops, offset, proj):
     got = y.double() - xd                 # (fp32 y = x + branch: at |x| ~ 300 the sum itself is only good to 2^-24 * 300 = 2e-5)
     err = float((got - branch).norm() / branch.norm())
     assert err < 1.2e-2, f'offset {offset} proj {proj}: branch error {err:.2e} against the exact sub-layer'
+
+
+@pytest.mark.parametrize('C', [512, 256])
+def test_proj_mlp_fused_small_m_shapes_are_the_same_arithmetic(ops, C):
+    """The kernel picks 1, 2 or 4 waves per workgroup by M (32- / 64- / 128-row tiles: at one clip the 128-row shape would leave 7 of 8
+    CUs idle).  A wave owns the same 32 rows and runs the same instruction sequence in every shape, so the first rows of a large call
+    and a small call on the same data must agree bit for bit."""
+    hidden, eps, Mbig = 1024, 1e-6, 40000
+    x = rnd(Mbig, C, seed=31) * (0.5 + rnd(Mbig, 1, seed=32).abs()) + 0.7 * rnd(Mbig, 1, seed=33)
+    o = rnd(Mbig, C, seed=34, dtype=BF)
+    wp = rnd(C, C, seed=35, dtype=BF, scale=0.05)
+    w1, w2 = rnd(hidden, C, seed=36, dtype=BF, scale=0.06), rnd(C, hidden, seed=37, dtype=BF, scale=0.04)
+    bp, b1, b2 = rnd(C, seed=38, scale=0.3), rnd(hidden, seed=39, scale=0.3), rnd(C, seed=40, scale=0.3)
+    rsum = w1.float().sum(1)
+    packed = ops.proj_mlp_pack_weights(wp, w1, w2)
+    big = torch.empty(Mbig, C, device=DEV)
+    ops.proj_mlp_fused_fwd(o, packed, bp, b1, b2, rsum, x, big, eps)          # 4 waves per workgroup
+    for M in (4131, 12000, 64, 33):                                            # 1 wave (<= 256 tiles of 32 rows), 2 waves, 1 wave, ragged
+        small = torch.full((M, C), float('nan'), device=DEV)
+        ops.proj_mlp_fused_fwd(o[:M].contiguous(), packed, bp, b1, b2, rsum, x[:M].contiguous(), small, eps)
+        assert torch.equal(small, big[:M]), f'M = {M}: differs from the 128-row shape'
