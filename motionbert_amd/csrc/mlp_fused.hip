@@ -135,20 +135,12 @@ __device__ long long* g_mlp_trace;
 #define MF_TSC(slot_) do { } while (0)
 #endif
 
-// NW (round 5): waves per workgroup, 4 (128-row tiles, the throughput shape) or 2 / 1 for SMALL M: at one clip (infer_wild.py:66-88,
-// M = 4131) the 128-row shape gives 33 workgroups on 256 CUs; with one wave per workgroup (32-row tiles) 130 CUs work, every wave
-// fetching the whole weight stream for its own rows (4 LDS-DMA pieces per wave where four waves issue one each).
-// s_waitcnt vmcnt(n), n known after constant folding
-__device__ __forceinline__ void mf_vmwait(int n) {
-    switch (n) {
-#define MW_(v_) case v_: asm volatile("s_waitcnt vmcnt(" #v_ ")" ::: "memory"); break;
-        MW_(8) MW_(10) MW_(16) MW_(18) MW_(20) MW_(32) MW_(36) MW_(40)
-#undef MW_
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-template <int C, bool PROJ = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 1) void mlp_fused_kernel(const bf16_t* __restrict__ xh, const char* __restrict__ wpk,
+// (Round 5, measured and dropped: 1 or 2 waves per workgroup -- 32- / 64-row tiles -- for small M, so that one clip (M = 4131,
+// infer_wild.py:66-88) occupies 130 CUs instead of 33.  Parity-green, bit-identical rows, and SLOWER: 0.092 ms per launch against
+// 0.087 (the forward of one clip 2.09 against 1.52 ms): a launch of less than one round takes ONE tile's critical path whatever the
+// number of workgroups, and a lone wave issues four times the LDS-DMA pieces.  profiles/r05_mlp_variants.txt)
+template <int C, bool PROJ = false>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const bf16_t* __restrict__ xh, const char* __restrict__ wpk,
                                                            const float* __restrict__ b1, const float* __restrict__ b2,
                                                            const float* __restrict__ rsum, int raw_in, const float* resid, float* y,
                                                            bf16_t* __restrict__ yb_out, float eps, float* __restrict__ mean_out,
@@ -169,9 +161,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_fused_kernel(const bf16_t* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ring 128 KiB | b1 [hidden] | rsum [hidden] | b2 [C] | XL KiB per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
-    static_assert(NW == 1 || NW == 2 || NW == 4, "waves per workgroup");
-    constexpr int PER = 4 / NW;            // LDS-DMA instructions per wave and 4-KiB piece of the weight stream
-    const int m0 = blockIdx.x * (32 * NW), mw = m0 + 32 * wave;
+    const int m0 = blockIdx.x * F_BM, mw = m0 + 32 * wave;
     char* const ring = smem;
     float* const b1s = reinterpret_cast<float*>(smem + F_RING);
     float* const rss = b1s + hidden;
@@ -192,8 +182,8 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_fused_kernel(const bf16_t* __r
     // phases of some CUs under the compute phases of the others -- 101.2 us per tile round with and 102.7-103.3 without, i.e. null:
     // the CUs are not phase-locked.  Prologue-only and epilogue-only builds run at 4.8 / 5.4 TB/s = ~11 B/clk per CU, the per-CU
     // miss-bandwidth limit, and that time ADDS to the loop's: profiles/r04_mlp_fused_ablation.txt.)
-    for (int k = tid; k < hidden; k += 64 * NW) { b1s[k] = b1[k]; rss[k] = raw_in ? rsum[k] : 0.f; }
-    for (int k = tid; k < C; k += 64 * NW) { b2s[k] = b2[k]; if (PROJ) bps[k] = bp[k] + b2[k]; }
+    for (int k = tid; k < hidden; k += 256) { b1s[k] = b1[k]; rss[k] = raw_in ? rsum[k] : 0.f; }
+    for (int k = tid; k < C; k += 256) { b2s[k] = b2[k]; if (PROJ) bps[k] = bp[k] + b2[k]; }
 
     // ---- X, the token operand of fc1, and the row constants of the raw-operand LayerNorm: fc1 = rstd acc + (b' - rstd mean rsum).
     //   xh given, raw_in = 0: xh is the normalised operand; constants (1, 0): fc1 = 1 acc + (b' + 0 rsum).
@@ -433,13 +423,11 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_fused_kernel(const bf16_t* __r
     // piece d of a stage = its fragments 4 d .. 4 d + 3, one per wave: this lane's 16 bytes sit at stage + 4096 d + 1024 wave + 16 lane
     const unsigned wvo = wave * 1024 + lane * 16;
     const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
-    // (NW < 4: KiB j of a piece belongs to wave j % NW; MF_ISSUE1K issues this wave's KiB number jj_ of its PER)
-#define MF_ISSUE1K(src_, slot_, d_, jj_) glds16_s((src_) + (d_) * 4096 + (jj_) * NW * 1024, wvo, dl + (slot_) * F_STAGE + (d_) * 4096 + (jj_) * NW * 1024)
-#define MF_ISSUE1(src_, slot_, d_) do { _Pragma("unroll") for (int jj_ = 0; jj_ < PER; ++jj_) MF_ISSUE1K(src_, slot_, d_, jj_); } while (0)
+#define MF_ISSUE1(src_, slot_, d_) glds16_s((src_) + (d_) * 4096, wvo, dl + (slot_) * F_STAGE + (d_) * 4096)
     // stage q + 1 has landed (this wave's pieces: counted wait; everyone's: barrier) and everyone is done with stage q - 1
 #define MF_SYNC(n_)                                                                                                  \
     do {                                                                                                             \
-        mf_vmwait((n_) * PER);                                                                                       \
+        asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         __builtin_amdgcn_s_barrier();                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -463,7 +451,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_fused_kernel(const bf16_t* __r
 #ifndef MBX_MLP_RING_DEEP
 #define MBX_MLP_RING_DEEP 1
 #endif
-    constexpr int RD = (MBX_MLP_RING_DEEP && NW > 1) ? 1 : 0;   // extra stages of run-ahead (NW = 1: 26 x 4 pieces in flight would not fit the 6-bit vmcnt)
+    constexpr int RD = MBX_MLP_RING_DEEP ? 1 : 0;               // extra stages of run-ahead
     constexpr int SYNC_SLOT = RD ? 32 - PF : 24;
     int q = 0;                                                  // stage sequence number
     {
@@ -505,10 +493,7 @@ __global__ __launch_bounds__(64 * NW, 1) void mlp_fused_kernel(const bf16_t* __r
             if (!(MBX_MLP_DBG & 4))                                                                                  \
                 fb[(k_ + PF) & 7] = k_ + PF < 32 ? lds_read16(st_, (k_ + PF) * 1024) : lds_read16(sn_, (k_ + PF - 32) * 1024); \
             if (!(MBX_MLP_DBG & 16) || (k_ & 15) == 0) MMA_(k_, fb[k_ & 7]);                                         \
-            if (((k_ & 3) + 1) % NW == 0 && !(MBX_MLP_DBG & 2)) {      /* NW = 4: slot 3 of every four; 2: slots 1, 3; 1: every slot */ \
-                if (k_ < 24) MF_ISSUE1K(n2_, l2_, (k_ >> 2) + 2, ((k_ & 3) + 1) / NW - 1);                           \
-                else MF_ISSUE1K(n3_, l3_, (k_ >> 2) - 6, ((k_ & 3) + 1) / NW - 1);                                   \
-            }                                                                                                        \
+            if ((k_ & 3) == 3 && !(MBX_MLP_DBG & 2)) { if (k_ < 24) MF_ISSUE1(n2_, l2_, (k_ >> 2) + 2); else MF_ISSUE1(n3_, l3_, (k_ >> 2) - 6); } \
             if (!(MBX_MLP_DBG & 1)) HOOK_(k_);                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
@@ -809,31 +794,19 @@ extern "C" int mbx_mlp_pack_weights(const void* w1, const void* w2, void* packed
     return 0;
 }
 
-// MBX_MLP_NW (A/B builds): force the waves per workgroup of the PROJ form (0 = by M, below)
-#ifndef MBX_MLP_NW
-#define MBX_MLP_NW 0
-#endif
-template <int C, bool PROJ, int NW = 4>
+template <int C, bool PROJ>
 static int launch_mlp_fused(const void* a, const void* packed, const float* b1, const float* b2, const float* rsum, int raw_in,
                             const float* resid, float* y, void* yb, float eps, float* mean, float* rstd, int M, int hidden, hipStream_t s,
                             const float* bp = nullptr) {
-    if constexpr (PROJ && NW == 4) {
-        // small M: more, smaller workgroups while they still fit ONE round of the chip (a 32-row workgroup streams the same 2.5 MiB of
-        // weights as a 128-row one: per row it is the costlier shape, so it only pays where CUs would otherwise idle)
-        const int cus = mbx_cu_count();
-        const int nw = MBX_MLP_NW ? MBX_MLP_NW : ((M + 31) / 32 <= cus ? 1 : ((M + 63) / 64 <= cus ? 2 : 4));
-        if (nw == 1) return launch_mlp_fused<C, PROJ, 1>(a, packed, b1, b2, rsum, raw_in, resid, y, yb, eps, mean, rstd, M, hidden, s, bp);
-        if (nw == 2) return launch_mlp_fused<C, PROJ, 2>(a, packed, b1, b2, rsum, raw_in, resid, y, yb, eps, mean, rstd, M, hidden, s, bp);
-    }
     const size_t shm = F_RING + (size_t)(2 * hidden + C) * sizeof(float) + (C == 512 ? 4 * 4096 : 0) + (PROJ ? C * sizeof(float) : 0);
-    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(mlp_fused_kernel<C, PROJ, NW>), shm, "mlp_fused_fwd")) return 1;
+    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(mlp_fused_kernel<C, PROJ>), shm, "mlp_fused_fwd")) return 1;
 #ifdef MBX_MLP_TRACE
     {
         static long long* const tb = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mlp_trace), &tb, sizeof(tb), 0, hipMemcpyHostToDevice, s);
     }
 #endif
-    hipLaunchKernelGGL((mlp_fused_kernel<C, PROJ, NW>), dim3((M + 32 * NW - 1) / (32 * NW)), dim3(64 * NW), shm, s, (const bf16_t*)a, (const char*)packed, b1, b2,
+    hipLaunchKernelGGL((mlp_fused_kernel<C, PROJ>), dim3((M + F_BM - 1) / F_BM), dim3(256), shm, s, (const bf16_t*)a, (const char*)packed, b1, b2,
                        rsum, raw_in, resid, y, (bf16_t*)yb, eps, mean, rstd, M, hidden, bp);
     MBX_LAUNCH_CHECK("mlp_fused_fwd");
     return 0;
