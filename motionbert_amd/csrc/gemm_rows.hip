@@ -70,6 +70,15 @@ __host__ __device__ constexpr int rows_vm_window(int p, bool own, bool prev) {
     return n;
 }
 
+// Diagnostic builds only (-DMBX_ROWS_TRACE, tools/rows_trace.py): 8 int64 per workgroup -- s_memrealtime (100 MHz) at entry, after the
+// prologue (operand in registers, first stages landed), after chunk 0, at half of the chunks, after the loop, after the last epilogue
+// with its stores acknowledged; the hardware id; the shader cycles of the whole workgroup.
+#ifdef MBX_ROWS_TRACE
+__device__ long long* g_rows_trace;
+#define RS_STAMP(slot_) do { tsr[slot_] = (long long)wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)      // (kept in scalar registers until the end)
+#else
+#define RS_STAMP(slot_) do { } while (0)
+#endif
 template <int K, int EPI, bool FROMX>
 __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict__ a, const char* __restrict__ wpk,
                                                          const float* __restrict__ bias, const float* __restrict__ rsum,
@@ -81,6 +90,11 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ring 64 KiB | 4 x 1 KiB store images | bias [N] | rsum [N]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
+#ifdef MBX_ROWS_TRACE
+    long long tsr[6] = {0, 0, 0, 0, 0, 0};
+    const long long cyc0 = (long long)__builtin_readcyclecounter();
+#endif
+    RS_STAMP(0);
     // Work units: the first `nfull` workgroups (whole rounds of the chip: 2 per CU) take one 128-row tile each and all of N; the row
     // tiles of the last, partial round are cut into `parts` column ranges, one workgroup each, so that the round that would leave
     // most CUs idle (64 clips: 4.03 rounds of 512 tiles) shrinks to a fraction of a tile time.
@@ -160,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
     // statements issued in between, drains the weight stream.
     __builtin_amdgcn_s_waitcnt(0x0070);                         // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();                               // the first stages and the biases are in LDS
+    RS_STAMP(1);
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
 
@@ -269,12 +284,17 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
 
     RS_TILE(0, false, false)                // chunk 0: tile 0 has no predecessor, the epilogue under tile 1 is the first
     RS_TILE(1, true, false)
+    RS_STAMP(2);
     for (int c = c0 + 1; c < c1; ++c) {
+#ifdef MBX_ROWS_TRACE
+        if (c == (c0 + c1) / 2) RS_STAMP(3);
+#endif
         ce = c - 1;
         RS_TILE(0, true, true)              // tile 1 of the previous chunk leaves
         ce = c;
         RS_TILE(1, true, true)              // tile 0 of this chunk
     }
+    RS_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-read tail stages have landed (nothing may arrive in LDS after the workgroup ends)
     if (MBX_ROWS_DBG & 1) return;
     asm volatile("s_nop 15" : "+v"(acc[1]));
@@ -283,6 +303,17 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
     RS_ESTEP(1, 0); RS_ESTEP(1, 1); RS_ESTEP(1, 2); RS_ESTEP(1, 3);
 #pragma unroll
     for (int r = 0; r < 2; ++r) { RS_TW1(r, 0); RS_TW1(r, 1); RS_TR(r); RS_TS(1, r); }
+#ifdef MBX_ROWS_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RS_STAMP(5);
+    if (g_rows_trace != nullptr && threadIdx.x == 0) {
+        long long* const tr = g_rows_trace + (size_t)blockIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tr[k] = tsr[k];
+        tr[6] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32);
+        tr[7] = (long long)__builtin_readcyclecounter() - cyc0;
+    }
+#endif
 }
 
 // ---- C ABI -------------------------------------------------------------------------------------------------------------------
@@ -309,6 +340,12 @@ static int launch_rows_nk(const void* a, const void* packed, const float* bias, 
     for (int pp = 8; pp > 1; --pp)
         if (nch % pp == 0 && (tiles - nfull) * pp <= slots) { parts = pp; break; }
     if (parts == 1) nfull = tiles;
+#ifdef MBX_ROWS_TRACE
+    {
+        static long long* const tb = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rows_trace), &tb, sizeof(tb), 0, hipMemcpyHostToDevice, s);
+    }
+#endif
     hipLaunchKernelGGL((rows_nk_kernel<K, EPI, FROMX>), dim3(nfull + (tiles - nfull) * parts), dim3(256), shm, s, a, (const char*)packed, bias,
                        rsum, mean, rstd, (bf16_t*)out, eps, M, N, nfull, parts);
     MBX_LAUNCH_CHECK("rows_gemm_nk");
