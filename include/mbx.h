@@ -41,9 +41,7 @@ enum mbx_epilogue {
     MBX_EPI_TANH  = 3, /* out_f = tanh(acc + bias)                    pre_logits fc + Tanh (:294-297,354)  */
     MBX_EPI_DGELU = 4, /* out_t = acc * gelu_erf'(aux_t)              backward of nn.GELU                  */
     MBX_EPI_LNBWD = 5, /* internal to mbx_gemm_nt_lnbwd (LayerNorm backward as a GEMM epilogue); not accepted by mbx_gemm_nt */
-    MBX_EPI_RESID_LN = 6, /* internal to mbx_gemm_nt_resid_ln (residual GEMM + the next LayerNorm forward); not accepted by mbx_gemm_nt */
-    MBX_EPI_RESID_T = 7,  /* internal to mbx_gemm_nt_resid_t (MBX_EPI_RESID + a bf16 copy of the output); not accepted by mbx_gemm_nt */
-    MBX_EPI_STORE_LN = 8, /* internal to mbx_gemm_nt_rawln (LayerNorm row constants applied in the epilogue); not accepted by mbx_gemm_nt */
+    /* 6, 7, 8: epilogues of rounds 3 / 4 that never had a caller in the default path; removed in round 5 */
     MBX_EPI_LNBWD_T = 9   /* internal to mbx_gemm_nt_lnbwd_t (MBX_EPI_LNBWD with the gradient residual stream in bf16) */
 };
 
@@ -98,20 +96,6 @@ size_t mbx_gemm_tn_ws(int M, int N, int K);
 int mbx_gemm_tn(const void* dy, const void* a, float* dw, float* db, int M, int N, int K, int dtype,
                 void* ws, void* stream);
 
-/* ---- residual GEMM + the LayerNorm that reads its output (bf16 path) ------------------------------------------------------
- * y[M,N] f32 = resid + a . w^T + bias (MBX_EPI_RESID: Block's x + attn(..) / x + mlp(..), DSTformer.py:241-249) and, from the
- * same launch, the next sub-layer's nn.LayerNorm over the rows of y (:241-249 norm*_s / norm*_t; LayerNorm forward of :79-85's
- * callers): xn bf16 [M,N], mean / rstd f32 [M].  gamma = beta = NULL: plain normalisation (folded path).  Arithmetic and results
- * identical to mbx_gemm_nt(MBX_EPI_RESID) followed by mbx_layernorm_fwd; the row block's last column-tile workgroup normalises
- * it out of L2.  N in {256, 512, 1024} (a full row), K % 64 == 0, y != resid.  ws: >= mbx_gemm_nt_resid_ln_ws(M) bytes.
- * Valid where workgroups with equal blockIdx & 7 share an XCD: mbx_xcc_probe writes the XCC id of each of `nblocks` workgroups
- * for the caller to check (hip_ops.can_fuse_resid_ln); the kernel verifies it again and traps instead of reading a stale row. */
-size_t mbx_gemm_nt_resid_ln_ws(int M);
-int mbx_gemm_nt_resid_ln(const void* a, const void* w, const float* bias, const float* resid, float* y, const float* gamma,
-                         const float* beta, float eps, void* xn, float* mean, float* rstd, int M, int N, int K, void* ws,
-                         void* stream);
-int mbx_xcc_probe(int* out, int nblocks, void* stream);
-
 /* ---- LayerNorm folded into the Linear it feeds (bf16 path) ---------------------------------------------------------------
  * Every norm1 / norm2 of a Block feeds exactly one Linear (DSTformer.py:241-249 -> Attention.qkv :143 / MLP.fc1 :80):
  *     Linear(LayerNorm(x)) = xhat . (W diag(gamma))^T + (b + W beta) = xhat . W'^T + b',   xhat = (x - mean) rstd.
@@ -152,13 +136,12 @@ int mbx_unfold_norm_grads(float* dw, const float* db, const float* w, const floa
 /* ---- LayerNorm as a raw operand + the fused MLP forward (bf16, no-grad / inference path) -------------------------------------
  * One step beyond the folding above.  With W' = W diag(gamma), b' = b + W beta, rsum[n] = sum_k W'[n,k] (mbx_fold_norm_weights):
  *     Linear(LayerNorm(y)) = rstd (y . W'^T - mean rsum) + b',
- * so the PRODUCER of a residual-stream tensor y (DSTformer.py:241-249: x + attn(..), x + mlp(..)) only leaves bf16(y) beside the
- * fp32 y, and the CONSUMER (the qkv / fc1 Linear behind norm1 / norm2) applies the row constants where its accumulators are:
- * the 32 stand-alone LayerNorm passes of a forward (read fp32 y, write bf16 xhat) disappear.
+ * so the CONSUMER of a residual-stream tensor y (the qkv / fc1 Linear behind norm1 / norm2, DSTformer.py:241-249) multiplies the
+ * RAW rows and applies the row constants where its accumulators are: the stand-alone LayerNorm passes of a forward (read fp32 y,
+ * write bf16 xhat) disappear.  The consumers read the fp32 rows of y themselves (mbx_rows_gemm_nk_ln, mbx_mlp_fused_fwd with
+ * a = NULL, mbx_proj_mlp_fused_fwd) and round the row SHIFTED by its first element, so that the rounding error scales with the
+ * spread of the row, not with its magnitude (LayerNorm does not see the shift).
  *
- * mbx_gemm_nt_resid_t: MBX_EPI_RESID (y f32 = resid + a . w^T + bias) + y_t = bf16(y).  N % 8 == 0, K % 64 == 0.
- * mbx_gemm_nt_rawln:   out_t bf16 [M,N] = rstd[m] (a . w^T - mean[m] rsum[n]) + bias[n]; a = bf16(y) [M,K] raw, (mean, rstd) the
- *                      LayerNorm statistics of the rows of y (f32 [M]), w / bias / rsum from mbx_fold_norm_weights.  N >= 256.
  * mbx_mlp_fused_fwd:   the whole MLP sub-layer of a Block (MLP.forward, DSTformer.py:79-85, inside :242 / :244 / :246 / :248)
  *     y = resid + fc2(gelu_erf(fc1(LN(.)))) in ONE kernel -- the [M, hidden] tensor never exists in HBM:
  *       a        bf16 [M,C]: raw_in = 0: the normalised operand xhat (mbx_layernorm_fwd / mbx_fuse_ln_fwd with gamma = NULL);
@@ -170,10 +153,6 @@ int mbx_unfold_norm_grads(float* dw, const float* db, const float* w, const floa
  *       b1 [hidden] (folded bias b'), b2 [C], rsum [hidden] (raw_in only), resid f32 [M,C] (= x; may alias y)
  *       y f32 [M,C];  y_t bf16 [M,C] = bf16(y) or NULL;  mean, rstd f32 [M] = LayerNorm statistics of the rows of y (eps) or NULL
  *     C in {256, 512}, hidden % 64 == 0, hidden <= 1536. */
-int mbx_gemm_nt_resid_t(const void* a, const void* w, const float* bias, const float* resid, float* y, void* y_t, int M, int N,
-                        int K, void* stream);
-int mbx_gemm_nt_rawln(const void* a, const void* w, const float* bias, const float* rsum, const float* mean, const float* rstd,
-                      void* out_t, int M, int N, int K, void* stream);
 size_t mbx_mlp_pack_bytes(int C, int hidden);
 int mbx_mlp_pack_weights(const void* w1, const void* w2, void* packed, int C, int hidden, void* stream);
 int mbx_mlp_fused_fwd(const void* a, int raw_in, const void* packed, const float* b1, const float* b2, const float* rsum,
@@ -194,7 +173,7 @@ int mbx_proj_mlp_fused_fwd(const void* o, const void* packed, const float* bp, c
  * owns 128 complete token rows: the token operand lives in registers, the weights stream as pre-packed MFMA fragments.
  * mbx_rows_pack_nk: w bf16 [N,K] row-major -> packed (mbx_rows_pack_bytes(N, K) bytes); K in {256, 512}, N % 64 == 0.
  * mbx_rows_gemm_nk: out bf16 [M,N] = a . w^T + bias (bias may be NULL);  with mean != NULL the raw-operand LayerNorm form of
- *                   mbx_gemm_nt_rawln: out = rstd[m] (a . w^T - mean[m] rsum[n]) + bias[n].
+*                   Linear: out = rstd[m] (a . w^T - mean[m] rsum[n]) + bias[n].
  * mbx_rows_gemm_nk_ln: the same from the fp32 rows x [M,K] of the residual stream themselves: operand bf16(x) rounded in the kernel,
  *                   (mean, rstd) of every row taken from the same loads (eps as in nn.LayerNorm): Linear(LayerNorm(x)) without a
  *                   LayerNorm pass and without a bf16 copy of x (norm1 + attn.qkv of a Block, DSTformer.py:241-249 / :139-143). */

@@ -5,14 +5,17 @@
 //                                   32x32x16 tiles), BK = 32, 4-stage 32 KiB LDS ring filled by LDS-DMA, ONE workgroup per CU,
 //                                   PING-PONG schedule (waves 4-7 one phase behind waves 0-3: while one wave of a SIMD reads its
 //                                   fragments the other issues its 16 MFMAs).  Epilogues: STORE (qkv, every plain dX GEMM),
-//                                   GELU (fc1), TANH (pre_logits), DGELU (+ the row dots of the folded LayerNorm backward),
-//                                   STORE_LN (round 4, no-grad path: LayerNorm row constants applied to the accumulator).
+//                                   GELU (fc1), TANH (pre_logits), DGELU (+ the row dots of the folded LayerNorm backward).
 //                                   X3 = the split-operand fp32-class mode (three bf16 passes over hi / lo planes).
 //   gemm_nt_pipe_kernel<EPI>        the same product on a 256 x 128 tile, 8 waves as 4 x 2 of 64 x 64, 3-stage 24 KiB ring, TWO
 //                                   workgroups per CU; carries the epilogues that stream fp32: RESID (proj, fc2: + residual),
-//                                   RESID_T (round 4: + a bf16 copy of the output), LNBWD / LNBWD_T (LayerNorm backward as the
-//                                   epilogue of the dX GEMM; _T: the gradient residual stream arrives and leaves as bf16),
-//                                   RESID_LN (opt-in: the row block's last column tile also normalises it).
+//                                   LNBWD / LNBWD_T (LayerNorm backward as the epilogue of the dX GEMM; _T: the gradient residual
+//                                   stream arrives and leaves as bf16).
+//                                   (Round 5: the three epilogues that never had a caller in the default path are gone from the
+//                                   source and the ABI -- RESID_LN, the residual GEMM whose last column tile normalises its row block
+//                                   (round 3: bit-identical, time-neutral, profiles/r03_resid_ln.txt), RESID_T / STORE_LN, the bf16
+//                                   interface of the first raw-operand LayerNorm (round 4; the row-owner kernels of gemm_rows.hip
+//                                   read the fp32 rows instead).  Their measurements stay in DESIGN.md; the code is in git history.)
 //   gemm_tn_pipe256_kernel<X3>      dW[N,K] = dY[M,N]^T . A[M,K] (contraction over the TOKEN dimension, the slow dimension of both
 //                                   operands): tiles staged untransposed, fragments fetched with the gfx950 transpose read
 //                                   ds_read_b64_tr_b16 (inline asm: see tr_frag_a), 256 x 256 output tile, token dimension split
@@ -103,92 +106,10 @@ static constexpr int P_NSTAGE = 3;
 // rows of 64 B = four 16-byte chunks; chunk c of row r at physical chunk c ^ ((r >> 2) & 3)
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * P_ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-// ---- LayerNorm forward as the TAIL of the residual GEMM (MBX_EPI_RESID_LN, round 3) -----------------------------------------
-// y = resid + a.Wt + b is the input of the next sub-layer's LayerNorm, and the ntn column tiles of a 256-row block finish within
-// microseconds of each other on CUs of ONE XCD (row-block-granular tile order below).  The last of them to finish normalises the
-// block's rows while they are still in that XCD's L2: the stand-alone LayerNorm launch (0.16 ms, 516 MB read back from HBM) goes
-// away.  Arithmetic = ln_fwd_row of elementwise.hip (two-pass, fp32), so xn / mean / rstd are bit-identical to the unfused pair.
-// Protocol: every wave waits for its stores (vmcnt(0)); barrier; thread 0 adds {1, xcc, xcc^2} to the row block's counter with ONE
-// atomic (count | sum << 8 | sum of squares << 16); the workgroup that sees count ntn - 1 is last.  Visibility needs no cache
-// maintenance BECAUSE all contributors share an L2 -- which the last workgroup verifies from the sums (all XCC ids equal its own,
-// else trap: never a silently stale row); the host enables the path only after mbx_xcc_probe confirmed the blockIdx -> XCD rule.
-// The CU's own L1 cannot hold a stale copy: it is invalid at kernel start and this kernel never read y before (y != resid is checked).
+// what the LayerNorm-backward epilogue with the bf16 gradient stream needs beside the common arguments
 struct NtLnTail {
     const bf16_t* dres_t;   // MBX_EPI_LNBWD_T: the incoming gradient of the residual stream as bf16 (instead of `resid` fp32)
-    float* mean;
-    float* rstd;
-    const float* gamma;     // NULL: plain normalisation (folded affine part)
-    const float* beta;
-    unsigned* cnt;          // [row blocks], zero on entry, zero on exit
-    float eps;
 };
-__device__ __forceinline__ unsigned mbx_xcc_id() {
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
-    return v;
-}
-template <int VPL>
-__device__ __forceinline__ void ln_tail_row(const float4 (&raw)[VPL], const float (&g)[VPL][4], const float (&bt)[VPL][4], float eps,
-                                            float invC, bf16_t* __restrict__ xn, float* __restrict__ mean, float* __restrict__ rstd,
-                                            size_t row, int N, int lane) {
-    float v[VPL][4];
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-        v[k][0] = raw[k].x; v[k][1] = raw[k].y; v[k][2] = raw[k].z; v[k][3] = raw[k].w;
-        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-    }
-    const float mu = wave_sum(s) * invC;
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < VPL; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[k][e] -= mu; q = fmaf(v[k][e], v[k][e], q); }
-    const float rs = 1.0f / sqrtf(wave_sum(q) * invC + eps);
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaf(v[k][e] * rs, g[k][e], bt[k][e]);
-        store4<bf16_t>(xn + row * N + (k * 64 + lane) * 4, o);
-    }
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-}
-// rows [m0, min(m0 + 256, M)) of y -> xn / mean / rstd; wave w owns rows m0 + w + 8 j, four rows per step (all loads first)
-template <int VPL>
-__device__ __forceinline__ void ln_tail_block(const float* y, bf16_t* __restrict__ xn, const NtLnTail& ln, int m0, int M, int N,
-                                              int wave, int lane) {
-    float g[VPL][4], bt[VPL][4];
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { g[k][e] = 1.f; bt[k][e] = 0.f; }
-        if (ln.gamma != nullptr) { load4<float>(ln.gamma + (k * 64 + lane) * 4, g[k]); load4<float>(ln.beta + (k * 64 + lane) * 4, bt[k]); }
-    }
-    const float invC = 1.0f / (float)N;
-    const int rows = min(P_BM, M - m0);
-    // software pipeline over the wave's 32 rows, G rows per step, fully unrolled: the loads of step s + 1 are in flight (in their own
-    // registers) while step s is reduced and stored, so a step costs one memory latency, not a store drain plus a load latency
-    constexpr int G = VPL >= 4 ? 2 : 4, NS = 32 / G;      // 64 registers of rows in flight whatever the row length
-    float4 raw[2][G][VPL];
-#define LN_TAIL_LOAD(buf_, step_)                                                                               \
-    _Pragma("unroll") for (int j_ = 0; j_ < G; ++j_) {                                                          \
-        const int r_ = min(wave + 8 * ((step_) * G + j_), rows - 1);                                            \
-        _Pragma("unroll") for (int k_ = 0; k_ < VPL; ++k_)                                                      \
-            raw[buf_][j_][k_] = *reinterpret_cast<const float4*>(y + (size_t)(m0 + r_) * N + (k_ * 64 + lane) * 4); \
-    }
-    LN_TAIL_LOAD(0, 0);
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        if (st + 1 < NS) { LN_TAIL_LOAD((st + 1) & 1, st + 1); }
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int r = wave + 8 * (st * G + j);
-            if (r < rows) ln_tail_row<VPL>(raw[st & 1][j], g, bt, ln.eps, invC, xn, ln.mean, ln.rstd, (size_t)(m0 + r), N, lane);
-        }
-    }
-#undef LN_TAIL_LOAD
-}
 
 // (Round 3, measured and dropped: a ninth PRODUCER wave per workgroup that issues all 24 LDS-DMA instructions of a k-tile, so
 // that no compute wave stalls on the vector-memory path in front of its MFMAs.  Correct, and 5-24 % slower on every shape
@@ -211,17 +132,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_pipe_kernel(const bf16_t* __re
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 stages x 24 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int lid;
-    if constexpr (EPI == MBX_EPI_RESID_LN) {
-        // row-block-granular order: XCD x (= blockIdx & 7) owns whole 256-row blocks, its workgroup `idx` is column tile idx % ntn of
-        // its row block idx / ntn; the grid is padded to 8 * ntn * ceil(row blocks / 8) workgroups
-        const int nrb = (M + P_BM - 1) / P_BM, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = nrb >> 3, r = nrb & 7, rbl = idx / ntn;
-        if (rbl >= q + (xcd < r ? 1 : 0)) return;
-        lid = ((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + rbl) * ntn + idx % ntn;
-    } else {
-        lid = xcd_remap2(blockIdx.x, gridDim.x);
-    }
+    const int lid = xcd_remap2(blockIdx.x, gridDim.x);
     const int n0 = (lid % ntn) * P_BN, m0 = (lid / ntn) * P_BM;
     const int nk = K / P_BK;
     const int wm = wave >> 1, wn = wave & 1;
@@ -408,7 +319,7 @@ constexpr int MBX_LNB_DEPTH = 2;
         // RESID: all eight residual loads of this half are issued BEFORE the accumulators are staged, so their HBM latency
         // runs under the LDS round trip (clamped addresses, unconditional: out-of-range lanes never store)
         float4 rr[8];
-        if (EPI == MBX_EPI_RESID || EPI == MBX_EPI_RESID_LN || EPI == MBX_EPI_RESID_T) {
+        if (EPI == MBX_EPI_RESID) {
 #pragma unroll
             for (int p = 0; p < 8; ++p)
                 rr[p] = epi_load_f4<MBX_LD_RES>(resid + (size_t)min(m0 + wm * 64 + p * 8 + erow0, M - 1) * N + min(n, N - 4));
@@ -435,10 +346,9 @@ constexpr int MBX_LNB_DEPTH = 2;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
                     store4<bf16_t>(out2_t + o, v);
-                } else if (EPI == MBX_EPI_RESID || EPI == MBX_EPI_RESID_LN || EPI == MBX_EPI_RESID_T) {
+                } else if (EPI == MBX_EPI_RESID) {
                     v[0] += rr[p].x; v[1] += rr[p].y; v[2] += rr[p].z; v[3] += rr[p].w;
                     epi_store16<MBX_ST_RES>(out_f + o, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
-                    if (EPI == MBX_EPI_RESID_T) store4<bf16_t>(out_t + o, v);      // the raw operand of the next sub-layer's Linear
                 } else if (EPI == MBX_EPI_TANH) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
@@ -457,30 +367,6 @@ constexpr int MBX_LNB_DEPTH = 2;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TSTAMP(2 + nk * 4);
 #undef TSTAMP
-    if constexpr (EPI == MBX_EPI_RESID_LN) {
-        // this wave's stores are in L2 (vmcnt(0) above); after the barrier, so are the workgroup's
-        __shared__ int s_last;
-        if (dbg & 32) return;      // diagnostics: no hand-shake, no tail (the residual GEMM in the row-block-granular order)
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) {
-            const unsigned xcc = mbx_xcc_id();
-            unsigned* c = ln.cnt + m0 / P_BM;
-            const unsigned old = __hip_atomic_fetch_add(c, 1u | (xcc << 8) | (xcc * xcc << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (old & 0xffu) == (unsigned)(ntn - 1);
-            if (last) {
-                const unsigned sx = ((old >> 8) & 0xffu) + xcc, sxx = (old >> 16) + xcc * xcc;
-                if (sx != (unsigned)ntn * xcc || sxx != (unsigned)ntn * xcc * xcc) __builtin_trap();   // a contributor ran on another XCD
-                __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_last = last;
-        }
-        __builtin_amdgcn_s_barrier();
-        if (!s_last || (dbg & 16)) return;      // dbg 16: hand-shake without the tail
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (N == 512) ln_tail_block<2>(out_f, out_t, ln, m0, M, N, wave, lane);
-        else if (N == 256) ln_tail_block<1>(out_f, out_t, ln, m0, M, N, wave, lane);
-        else ln_tail_block<4>(out_f, out_t, ln, m0, M, N, wave, lane);
-    }
 }
 
 // ================================================================================================
@@ -580,15 +466,11 @@ __device__ __forceinline__ void nt_epilogue(f32x16_t (&acc)[NTN][4], char* er, c
 // such an epilogue is store-ISSUE bound, not bandwidth bound (guide T21): half the store instructions for the same bytes.
 // Staging tile: 32 rows x 64 bf16, row pitch 144 B (16-byte aligned rows for ds_read_b128); GELU stages two tiles.
 static constexpr int EB_PITCH = 64 * 2 + 16, EB_TILE = 32 * EB_PITCH;   // 4608 B
-// STORE_LN (the no-grad path): the A operand was the RAW bf16 row y and the LayerNorm in front of this Linear is applied here,
-//     out = rstd (acc - mean rsum[n]) + b'[n]   (W' = W diag(gamma), b' = b + W beta, rsum = row sums of the rounded W'),
-// with the row constants (mean, rstd) of y from its producer: rows are lanes in the accumulator layout, so they are two registers.
 template <int EPI, int NTN, bool FULL>
 __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* er, const float* __restrict__ bias,
                                                  bf16_t* __restrict__ out_t, bf16_t* __restrict__ out2_t, int M, int N,
-                                                 int row_base, int col_base, int lane, const float* __restrict__ ln_rsum = nullptr,
-                                                 const float* __restrict__ ln_mean = nullptr, const float* __restrict__ ln_rstd = nullptr) {
-    static_assert(EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU || EPI == MBX_EPI_STORE_LN, "bf16 staging: STORE / GELU / STORE_LN only");
+                                                 int row_base, int col_base, int lane) {
+    static_assert(EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU, "bf16 staging: STORE / GELU only");
     const int i = lane & 31, g = lane >> 5;
     const int rr = lane >> 3, cc = (lane & 7) * 8;
     char* er2 = er + EB_TILE;
@@ -603,26 +485,9 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                 bb[tn][q][0] = bb[tn][q][1] = bb[tn][q][2] = bb[tn][q][3] = 0.f;
                 if (bias && (FULL || nb < N)) load4<float>(bias + nb, bb[tn][q]);
             }
-        float rsm[EPI == MBX_EPI_STORE_LN ? 2 : 1][4][4];
-        if (EPI == MBX_EPI_STORE_LN) {
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int nb = col_base + h * 64 + tn * 32 + 8 * q + 4 * g;
-                    rsm[tn][q][0] = rsm[tn][q][1] = rsm[tn][q][2] = rsm[tn][q][3] = 0.f;
-                    if (FULL || nb < N) load4<float>(ln_rsum + nb, rsm[tn][q]);
-                }
-        }
         const int n = col_base + h * 64 + cc;
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
-            float ln_rs = 1.f, ln_k = 0.f;
-            if (EPI == MBX_EPI_STORE_LN) {
-                const int mr = min(row_base + tm * 32 + i, M - 1);
-                ln_rs = ln_rstd[mr];
-                ln_k = -ln_rs * ln_mean[mr];
-            }
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -630,10 +495,9 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        v[e] = EPI == MBX_EPI_STORE_LN ? fmaf(ln_rs, acc[2 * h + tn][tm][4 * q + e], fmaf(ln_k, rsm[tn][q][e], bb[tn][q][e]))
-                                                       : acc[2 * h + tn][tm][4 * q + e] + bb[tn][q][e];
+                        v[e] = acc[2 * h + tn][tm][4 * q + e] + bb[tn][q][e];
                     const int off = i * EB_PITCH + (tn * 32 + 8 * q + 4 * g) * 2;
-                    if (EPI == MBX_EPI_STORE || EPI == MBX_EPI_STORE_LN) {
+                    if (EPI == MBX_EPI_STORE) {
                         *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     } else {
                         if (out_t) *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
@@ -654,7 +518,7 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                 const int m = row_base + tm * 32 + p * 8 + rr;
                 if (FULL || (m < M && n < N)) {     // FULL: the wave's whole 128 x 64 NTN/2 block is inside the matrix (no branches)
                     const size_t o = (size_t)m * N + n;
-                    if (EPI == MBX_EPI_STORE || EPI == MBX_EPI_STORE_LN) {
+                    if (EPI == MBX_EPI_STORE) {
                         epi_store16<MBX_ST_PP>(out_t + o, t1[p]);
                     } else {
                         if (out_t) epi_store16<MBX_ST_PP>(out_t + o, t1[p]);
@@ -752,18 +616,17 @@ __device__ __forceinline__ void nt256_epilogue(f32x16_t (&acc)[2][4], char* smem
                                                const float* __restrict__ resid, const TO* __restrict__ aux, int M, int N, int m0,
                                                int n0, int wave, int lane, const float* __restrict__ st_bias = nullptr,
                                                const float* __restrict__ st_rsum = nullptr, float* __restrict__ st_part = nullptr,
-                                               const float* __restrict__ ln_mean = nullptr, const float* __restrict__ ln_rstd = nullptr,
                                                bf16_t* __restrict__ pl_hi = nullptr, bf16_t* __restrict__ pl_lo = nullptr) {
     __builtin_amdgcn_s_barrier();   // every wave is done with the k-loop's LDS stages
     char* er = smem + wave * Q_EPI_WAVE_BYTES;
     const int row_base = m0 + (wave >> 2) * 128, col_base = n0 + (wave & 3) * 64;
     if constexpr (sizeof(TO) == 4) {      // fp32-class mode (bf16x3): every T-typed tensor is fp32
         nt_epilogue<EPI, 2, TO>(acc, er, bias, out_t, out2_t, out_f, resid, aux, M, N, row_base, col_base, lane, pl_hi, pl_lo);
-    } else if constexpr (EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU || EPI == MBX_EPI_STORE_LN) {
+    } else if constexpr (EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU) {
         if (row_base + 128 <= M && col_base + 64 <= N)
-            nt_epilogue_bf16<EPI, 2, true>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane, st_rsum, ln_mean, ln_rstd);
+            nt_epilogue_bf16<EPI, 2, true>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane);
         else
-            nt_epilogue_bf16<EPI, 2, false>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane, st_rsum, ln_mean, ln_rstd);
+            nt_epilogue_bf16<EPI, 2, false>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane);
     }
     else if constexpr (EPI == MBX_EPI_DGELU)
         nt_epilogue_dgelu<2>(acc, er, out_t, aux, M, N, row_base, col_base, lane, st_bias, st_rsum, st_part);
@@ -877,8 +740,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
                                                                const float* __restrict__ resid, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ aux,
                                                                int M, int N, int K, int ntn,
                                                                const float* __restrict__ st_bias, const float* __restrict__ st_rsum,
-                                                               float* __restrict__ st_part, const float* __restrict__ ln_mean,
-                                                               const float* __restrict__ ln_rstd, bf16_t* __restrict__ pl_hi,
+                                                               float* __restrict__ st_part, bf16_t* __restrict__ pl_hi,
                                                                bf16_t* __restrict__ pl_lo
 #ifdef MBX_DIAG
                                                                , long long* trace      // cycle stamps: diagnostic builds only
@@ -1019,7 +881,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp256_kernel(const bf16_t* __r
 #undef PSTAMP
     if (!trailing) __builtin_amdgcn_s_barrier();   // pairs with the trailing group's last phase
 
-    nt256_epilogue<EPI, TO>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane, st_bias, st_rsum, st_part, ln_mean, ln_rstd, pl_hi, pl_lo);
+    nt256_epilogue<EPI, TO>(acc, smem, bias, out_t, out2_t, out_f, resid, aux, M, N, m0, n0, wave, lane, st_bias, st_rsum, st_part, pl_hi, pl_lo);
 #ifdef MBX_DIAG
     if (trace != nullptr && blockIdx.x == 3000 && (tid == 0 || tid == 256)) {
         long long* const tr2 = trace + (tid == 256 ? 2048 : 0);
@@ -1037,8 +899,7 @@ static int set_lds_attr(K kernel, size_t bytes, const char* who) {
 
 static int launch_nt256(const void* a, const void* w, const float* bias, int epi, void* out_t, void* out2_t, float* out_f,
                         const float* resid, const void* aux, int M, int N, int K, hipStream_t s, const float* st_bias = nullptr,
-                        const float* st_rsum = nullptr, float* st_part = nullptr, const float* ln_mean = nullptr,
-                        const float* ln_rstd = nullptr) {
+                        const float* st_rsum = nullptr, float* st_part = nullptr) {
     const int ntn = (N + Q_BN - 1) / Q_BN, ntm = (M + Q_BM - 1) / Q_BM;
     dim3 grid((unsigned)ntn * ntm), block(512);
     const size_t shm = Q_NSTAGE * Q_STAGE;
@@ -1046,8 +907,8 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
     static const int pp = mbx_env_int("MBX_NT_PP", MBX_NT_PP_DEFAULT);
 #define MBX_Q_LOCKSTEP(E)                                                                                             \
         if (!pp) {                                                                                                    \
-            if (st_part != nullptr || ln_mean != nullptr)                                                             \
-                return mbx_set_error("gemm_nt: the lockstep loop (MBX_NT_PP=0, diagnostic builds) has no row-dot / raw-operand epilogue"); \
+            if (st_part != nullptr)                                                                                   \
+                return mbx_set_error("gemm_nt: the lockstep loop (MBX_NT_PP=0, diagnostic builds) has no row-dot epilogue"); \
             if (set_lds_attr(gemm_nt_pipe256_kernel<E>, shm, "gemm_nt_pipe256")) return 1;                            \
             hipLaunchKernelGGL((gemm_nt_pipe256_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w, bias, \
                                (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn);      \
@@ -1066,7 +927,7 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E>), grid, block, shm, s, (const bf16_t*)a, (const bf16_t*)w,        \
                            (const bf16_t*)nullptr, (const bf16_t*)nullptr, bias,                                      \
                            (bf16_t*)out_t, (bf16_t*)out2_t, out_f, resid, (const bf16_t*)aux, M, N, K, ntn,          \
-                           st_bias, st_rsum, st_part, ln_mean, ln_rstd, (bf16_t*)nullptr, (bf16_t*)nullptr MBX_Q_TRACE_ARG); \
+                           st_bias, st_rsum, st_part, (bf16_t*)nullptr, (bf16_t*)nullptr MBX_Q_TRACE_ARG); \
         break;
     switch (epi) {
         MBX_Q_CASE(MBX_EPI_STORE)
@@ -1074,7 +935,6 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
         MBX_Q_CASE(MBX_EPI_RESID)
         MBX_Q_CASE(MBX_EPI_TANH)
         MBX_Q_CASE(MBX_EPI_DGELU)
-        MBX_Q_CASE(MBX_EPI_STORE_LN)
         default: return mbx_set_error("gemm_nt: unknown epilogue %d", epi);
     }
 #undef MBX_Q_CASE
@@ -1101,8 +961,8 @@ int mbx_launch_gemm_nt_x3(const void* a_hi, const void* a_lo, const void* w_hi, 
         if (set_lds_attr(gemm_nt_pp256_kernel<E, true>, shm, "gemm_nt_x3")) return 1;                                 \
         hipLaunchKernelGGL((gemm_nt_pp256_kernel<E, true>), grid, block, shm, s, (const bf16_t*)a_hi, (const bf16_t*)w_hi, \
                            (const bf16_t*)a_lo, (const bf16_t*)w_lo, bias, out_t, out2_t, out_f, resid, aux, M, N, K, ntn, \
-                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (const float*)nullptr,      \
-                           (const float*)nullptr, (bf16_t*)pl_hi, (bf16_t*)pl_lo MBX_X3_TRACE_ARG);                   \
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (bf16_t*)pl_hi, (bf16_t*)pl_lo \
+                           MBX_X3_TRACE_ARG);                                                                        \
         break;
     switch (epi) {
         MBX_X3_CASE(MBX_EPI_STORE)
@@ -1205,77 +1065,6 @@ extern "C" int mbx_gemm_nt_lnbwd_t(const void* a, const void* w, const void* xha
 #endif
                        );
     MBX_LAUNCH_CHECK("gemm_nt_lnbwd_t");
-    return 0;
-}
-
-// out_t = rstd (a . Wt - mean rsum) + b: the Linear behind a LayerNorm whose input row arrives RAW (a = bf16(y)) with its row
-// statistics -- the consumer side of include/mbx.h "LayerNorm as a raw operand" (qkv of the no-grad path)
-extern "C" int mbx_gemm_nt_rawln(const void* a, const void* w, const float* bias, const float* rsum, const float* mean, const float* rstd,
-                                 void* out_t, int M, int N, int K, void* stream) {
-    MBX_CHECK_ARG(a && w && bias && rsum && mean && rstd && out_t, "gemm_nt_rawln: null pointer");
-    MBX_CHECK_ARG(M > 0 && N >= 256 && N % 8 == 0 && K > 0 && K % 64 == 0, "gemm_nt_rawln: bad shape M=%d N=%d K=%d (N >= 256, N %% 8, K %% 64)", M, N, K);
-    return launch_nt256(a, w, bias, MBX_EPI_STORE_LN, out_t, nullptr, nullptr, nullptr, nullptr, M, N, K, (hipStream_t)stream, nullptr, rsum,
-                        nullptr, mean, rstd);
-}
-// y = resid + a . Wt + b (fp32) and y_t = bf16(y): the residual GEMM of the no-grad path, whose consumer takes the LayerNorm of y
-// as a raw operand (include/mbx.h "LayerNorm as a raw operand")
-extern "C" int mbx_gemm_nt_resid_t(const void* a, const void* w, const float* bias, const float* resid, float* y, void* y_t, int M,
-                                   int N, int K, void* stream) {
-    MBX_CHECK_ARG(a && w && resid && y && y_t, "gemm_nt_resid_t: null pointer");
-    MBX_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && K > 0 && K % 64 == 0, "gemm_nt_resid_t: bad shape M=%d N=%d K=%d (N %% 8, K %% 64)", M, N, K);
-    const int ntn = (N + P_BN - 1) / P_BN, ntm = (M + P_BM - 1) / P_BM;
-    const size_t shm = P_NSTAGE * P_STAGE;
-    if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_RESID_T>, shm, "gemm_nt_resid_t")) return 1;
-    hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_RESID_T>), dim3((unsigned)ntn * ntm), dim3(512), shm, (hipStream_t)stream, (const bf16_t*)a,
-                       (const bf16_t*)w, bias, (bf16_t*)y_t, (bf16_t*)nullptr, y, resid, (const bf16_t*)nullptr, M, N, K, ntn,
-                       (const float4*)nullptr, (const float*)nullptr, NtLnTail{}
-#ifdef MBX_DIAG
-                       , 0, (long long*)nullptr
-#endif
-                       );
-    MBX_LAUNCH_CHECK("gemm_nt_resid_t");
-    return 0;
-}
-
-// y = resid + a . Wt + b  and, from the same launch,  xn = LayerNorm(y) (gamma / beta, or plain normalisation when both are NULL),
-// mean, rstd: the residual GEMM (DSTformer.py:241-249) followed by the next sub-layer's norm.  N = 256, 512 or 1024 (a full row).
-extern "C" size_t mbx_gemm_nt_resid_ln_ws(int M) { return (size_t)((M + P_BM - 1) / P_BM) * sizeof(unsigned); }
-extern "C" int mbx_gemm_nt_resid_ln(const void* a, const void* w, const float* bias, const float* resid, float* y, const float* gamma,
-                                    const float* beta, float eps, void* xn, float* mean, float* rstd, int M, int N, int K, void* ws,
-                                    void* stream) {
-    MBX_CHECK_ARG(a && w && resid && y && xn && mean && rstd && ws, "gemm_nt_resid_ln: null pointer");
-    MBX_CHECK_ARG((gamma && beta) || (!gamma && !beta), "gemm_nt_resid_ln: gamma and beta come together (both NULL = plain normalisation)");
-    MBX_CHECK_ARG(M > 0 && (N == 256 || N == 512 || N == 1024) && K > 0 && K % 64 == 0,
-                  "gemm_nt_resid_ln: bad shape M=%d N=%d K=%d (N in {256, 512, 1024}, K %% 64)", M, N, K);
-    MBX_CHECK_ARG(y != resid, "gemm_nt_resid_ln: y must not alias resid");
-    const int ntn = N / P_BN, ntm = (M + P_BM - 1) / P_BM;
-    const size_t shm = P_NSTAGE * P_STAGE;
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, mbx_gemm_nt_resid_ln_ws(M), s) != hipSuccess) return mbx_set_error("gemm_nt_resid_ln: counter reset failed");
-#ifdef MBX_DIAG
-    static const int dbg = mbx_env_int("MBX_DBG", 0);
-#endif
-    if (set_lds_attr(gemm_nt_pipe_kernel<MBX_EPI_RESID_LN>, shm, "gemm_nt_resid_ln")) return 1;
-    const NtLnTail ln{nullptr, mean, rstd, gamma, beta, (unsigned*)ws, eps};
-    hipLaunchKernelGGL((gemm_nt_pipe_kernel<MBX_EPI_RESID_LN>), dim3((unsigned)(8 * ntn * ((ntm + 7) / 8))), dim3(512), shm, s, (const bf16_t*)a,
-                       (const bf16_t*)w, bias, (bf16_t*)xn, (bf16_t*)nullptr, y, resid, (const bf16_t*)nullptr, M, N, K, ntn,
-                       (const float4*)nullptr, (const float*)nullptr, ln
-#ifdef MBX_DIAG
-                       , dbg, (long long*)nullptr
-#endif
-                       );
-    MBX_LAUNCH_CHECK("gemm_nt_resid_ln");
-    return 0;
-}
-// XCC id of every workgroup of a launch of `nblocks` one-wave workgroups: the host checks that workgroups with equal blockIdx & 7
-// share an XCD before it enables mbx_gemm_nt_resid_ln (hip_ops.can_fuse_resid_ln)
-__global__ void xcc_probe_kernel(int* out) {
-    if (threadIdx.x == 0) out[blockIdx.x] = (int)mbx_xcc_id();
-}
-extern "C" int mbx_xcc_probe(int* out, int nblocks, void* stream) {
-    MBX_CHECK_ARG(out && nblocks > 0, "xcc_probe: bad arguments");
-    hipLaunchKernelGGL(xcc_probe_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, out);
-    MBX_LAUNCH_CHECK("xcc_probe");
     return 0;
 }
 

@@ -172,9 +172,6 @@ class Engine:
         self.Pk: Dict[str, torch.Tensor] = {}       # fc1 / fc2 of every MLP (with the proj in front of it) in the fragment order of the fused kernels
         self.Pk_proj: Dict[str, str] = {}           # MLP -> the proj Linear packed in front of it (derived from ORDER)
         self.proj_mlp = os.environ.get('MBX_PROJ_MLP', '1') == '1' and hasattr(ops, 'proj_mlp_fused_fwd')      # A/B switch: 0 = proj + residual as its own GEMM
-        # residual GEMM + the next LayerNorm forward in one launch (round 3, bf16 path; include/mbx.h): decided at the first forward
-        # (the provider checks the device's workgroup -> XCD rule once).  Opt-in with MBX_RESID_LN=1: measured time-neutral at 64 clips
-        self.resid_ln = None
 
     def _streams(self):
         """(main, side) streams for the dual-stream schedule, or (None, None)."""
@@ -331,8 +328,6 @@ class Engine:
             B = 2 * B
         M, C = B * T * J, cfg.C
         self.B, self.Tlen, self.M = B, T, M
-        if self.resid_ln is None:
-            self.resid_ln = (not self.x3) and bool(getattr(ops, 'can_fuse_resid_ln', lambda *_: False)(self.T, cfg.C, x.device))
         self.rawln = (not need_grad and self.fold and self.drop_seed is None and self.rawln_allowed and
                       bool(getattr(ops, 'can_fuse_mlp', lambda *_: False)(self.T, cfg)))
         self.prepare_weights(need_grad)
@@ -419,8 +414,8 @@ class Engine:
         return out, saved
 
     def _block_fwd(self, x, pre, kind, need_grad, ln=None):
-        """`ln` = (xn, mean, rstd) of x when its producer already normalised it: the fusion kernel of the previous level for the
-        first sub-layer, the residual GEMM of the previous sub-layer for the others (`gemm_nt_resid_ln`); never anything else."""
+        """`ln` = (xn, mean, rstd) of x when its producer already normalised it (the fusion kernel of the previous level, for the
+        first sub-layer of a Block); never anything else."""
         svs = []
         order = ORDER[kind]
         pend = None      # no-grad: an attention whose proj + residual has been left to the MLP kernel that follows: dict(o=, proj=)
@@ -437,22 +432,12 @@ class Engine:
         return x, svs
 
     def _resid_gemm(self, a, lin, x, dm, pre, nxt):
-        """y = x + a . W^T + b (fp32 residual stream).  When the output feeds the LayerNorm `nxt` of the same Block and nothing
-        touches y in between (no branch dropout), the same launch also writes that LayerNorm's output: returns (y, ln or None)."""
+        """y = x + a . W^T + b (fp32 residual stream): returns (y, None) -- the second value is the `ln` slot of the next sub-layer,
+        which no residual GEMM fills since round 5 (the opt-in kernel that also normalised its row block is gone)."""
         cfg, ops, P = self.cfg, self.ops, self.P
-        M, C = self.M, cfg.C
-        y = self._f(M, C)
-        drop = dm is not None and (dm[0] > 0 or dm[3] > 0)
-        if self.rawln:      # no-grad: the next sub-layer makes its operand and its LayerNorm statistics from the fp32 rows of y itself
-            ops.gemm_nt(a, self.Wn[lin], P[lin + '.bias'], EPI_RESID, resid=x, out_f=y)
-            return y, None
-        if nxt is not None and not drop and self.resid_ln:
-            xn, mean, rstd = self._t(M, C), self._f(M), self._f(M)
-            g, b = (None, None) if self.fold else (P[f'{pre}.{nxt}.weight'], P[f'{pre}.{nxt}.bias'])
-            ops.gemm_nt_resid_ln(a, self.Wn[lin], P[lin + '.bias'], x, y, g, b, cfg.eps, xn, mean, rstd)
-            return y, (xn, mean, rstd)
+        y = self._f(self.M, cfg.C)
         ops.gemm_nt(a, self.Wn[lin], P[lin + '.bias'], EPI_RESID, resid=x, out_f=y)
-        if drop:      # proj_drop / MLP drop + DropPath on the branch (DSTformer.py:84,148-149,241-242)
+        if (not self.rawln) and dm is not None and (dm[0] > 0 or dm[3] > 0):      # proj_drop / MLP drop + DropPath on the branch (DSTformer.py:84,148-149,241-242)
             ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])
         return y, None
 

@@ -41,13 +41,8 @@ SIGNATURES = {
     'mbx_lnbwd_rowc': (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     'mbx_gemm_nt_lnbwd': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
     'mbx_gemm_nt_lnbwd_t': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
-    'mbx_gemm_nt_resid_ln_ws': (_sz, [_i]),
-    'mbx_gemm_nt_resid_ln': (_i, [_vp] * 7 + [_f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    'mbx_xcc_probe': (_i, [_vp, _i, _vp]),
     'mbx_unfold_norm_grads_ws': (_sz, [_i, _i]),
     'mbx_unfold_norm_grads': (_i, [_vp] * 7 + [_i, _i, _vp, _vp]),
-    'mbx_gemm_nt_resid_t': (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
-    'mbx_gemm_nt_rawln': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
     'mbx_mlp_pack_bytes': (_sz, [_i, _i]),
     'mbx_mlp_pack_weights': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'mbx_proj_mlp_pack_bytes': (_sz, [_i, _i]),
@@ -126,7 +121,6 @@ class HipOps:
         self.lib = lib or load_library()
         self._ws_cache: Dict[tuple, int] = {}
         self._desc_cache: Dict[tuple, dict] = {}
-        self._xcc_ok: Dict[int, bool] = {}
         self.weight_cache: Dict[int, tuple] = {}      # device index -> (key, prepared weights) of the last no-grad forward (engine.prepare_weights)
         self._lock = threading.Lock()
 
@@ -320,7 +314,7 @@ class HipOps:
         return packed
 
     def rows_gemm_nk(self, a_t, packed, bias, out_t, rsum=None, mean=None, rstd=None):
-        """out_t bf16 [M,N] = a . w^T + bias, or with (rsum, mean, rstd) the raw-operand LayerNorm form of gemm_nt_rawln."""
+        """out_t bf16 [M,N] = a . w^T + bias, or with (rsum, mean, rstd) the raw-operand LayerNorm form out = rstd (a . w^T - mean rsum) + bias."""
         M, K = a_t.shape
         self._ck(self.lib.mbx_rows_gemm_nk(_p(a_t), _p(packed), _p(bias), _p(rsum), _p(mean), _p(rstd), _p(out_t), M, out_t.shape[1], K,
                                            self._stream()))
@@ -330,15 +324,6 @@ class HipOps:
         in the kernel (no LayerNorm pass, no bf16 copy of the residual stream)."""
         M, K = x.shape
         self._ck(self.lib.mbx_rows_gemm_nk_ln(_p(x), _p(packed), _p(bias), _p(rsum), float(eps), _p(out_t), M, out_t.shape[1], K, self._stream()))
-
-    def gemm_nt_resid_t(self, a_t, w_t, bias, resid, y, y_t):
-        M, K = a_t.shape
-        self._ck(self.lib.mbx_gemm_nt_resid_t(_p(a_t), _p(w_t), _p(bias), _p(resid), _p(y), _p(y_t), M, w_t.shape[0], K, self._stream()))
-
-    def gemm_nt_rawln(self, a_t, w_t, bias, rsum, mean, rstd, out_t):
-        M, K = a_t.shape
-        self._ck(self.lib.mbx_gemm_nt_rawln(_p(a_t), _p(w_t), _p(bias), _p(rsum), _p(mean), _p(rstd), _p(out_t), M, w_t.shape[0], K,
-                                            self._stream()))
 
     # ------------------------------------------------------------------ measurement aid (bench.py, tools/clock_power.py)
     def mfma_probe(self, seconds: float = 0.25, wgs_per_cu: int = 1, device=None):
@@ -364,37 +349,6 @@ class HipOps:
         st = ws[n_wg * 1024:].view(torch.int64).view(n_wg, 2).cpu().double()
         clock = float((st[:, 0] / (st[:, 1] * 1e-8)).median()) / 1e9
         return dict(tflops=flops.value / ms / 1e9, clock_ghz=clock, ms=ms, iters=iters, wgs_per_cu=wgs_per_cu)
-
-    # ------------------------------------------------------------------ residual GEMM + the next LayerNorm (bf16 path)
-    def can_fuse_resid_ln(self, tdtype, N: int, device=None) -> bool:
-        """`gemm_nt_resid_ln` normalises a 256-row block of y in the last of its column-tile workgroups to finish, out of the L2
-        all of them wrote through -- valid when workgroups with equal blockIdx & 7 run on one XCD.  Checked once per device with
-        mbx_xcc_probe (and again by the kernel itself, which traps rather than read a stale row).
-        Opt-in (MBX_RESID_LN=1): bit-identical to the two launches it replaces and 30 launches per step fewer, but at 64 clips the
-        tail costs what the stand-alone LayerNorm cost (the rows have left L2 by the time the last tile is done): 126.2 vs 126.0 ms
-        per step (profiles/r03_resid_ln.txt)."""
-        if tdtype != torch.bfloat16 or N not in (256, 512, 1024) or os.environ.get('MBX_RESID_LN', '0') != '1':
-            return False
-        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
-        ok = self._xcc_ok.get(dev.index)
-        if ok is None:
-            ok = True
-            for nb in (8 * 67, 8 * 517 + 3):
-                out = torch.full((nb,), -1, dtype=torch.int32, device=dev)
-                self._ck(self.lib.mbx_xcc_probe(_p(out), nb, self._stream()))
-                ids = out.cpu()
-                cls = torch.arange(nb) % 8
-                ok = ok and all(len(set(ids[cls == c].tolist())) == 1 for c in range(8)) and int(ids.min()) >= 0
-            self._xcc_ok[dev.index] = ok
-        return ok
-
-    def gemm_nt_resid_ln(self, a_t, w_t, bias, resid, y, gamma, beta, eps, xn, mean, rstd):
-        """y = resid + a . Wt + bias (fp32) and xn = LayerNorm(y) (gamma / beta, or plain normalisation with None / None), mean, rstd."""
-        M, K = a_t.shape
-        N = w_t.shape[0]
-        ws = self._ws(('rln', M), self.lib.mbx_gemm_nt_resid_ln_ws, M, device=y.device)
-        self._ck(self.lib.mbx_gemm_nt_resid_ln(_p(a_t), _p(w_t), _p(bias), _p(resid), _p(y), _p(gamma), _p(beta), float(eps), _p(xn), _p(mean),
-                                               _p(rstd), M, N, K, _p(ws), self._stream()))
 
     def unfold_norm_grads(self, dw, db, w, gamma, beta, dgamma, dbeta):
         N, K = dw.shape

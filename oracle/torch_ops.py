@@ -216,25 +216,7 @@ class MockOps:
             raise ValueError(epi)
 
     layernorm_fwd_planes_ok = True      # producers accept a (hi, lo) pair where a bf16x3 GEMM operand is due
-    fuse_resid_ln = True      # tests switch it off to exercise the unfused sequencing
     grad_stream_t = True      # gemm_nt_lnbwd takes a T-typed dres and may skip the fp32 dx (the gradient stream inside a Block)
-
-    def can_fuse_resid_ln(self, tdtype, N, device=None):
-        return bool(self.fuse_resid_ln)
-
-    def gemm_nt_resid_ln(self, a_t, w_t, bias, resid, y, gamma, beta, eps, xn, mean, rstd):
-        """y = resid + a . w^T + bias;  xn, mean, rstd = LayerNorm forward of y (gamma = beta = None: plain normalisation)."""
-        self._log('gemm_nt.resid_ln')
-        acc = a_t.float() @ w_t.float().t()
-        if bias is not None:
-            acc = acc + bias
-        y.copy_(resid + acc)
-        mu = y.mean(-1)
-        rs = torch.rsqrt(((y - mu[:, None]) ** 2).mean(-1) + eps)
-        mean.copy_(mu)
-        rstd.copy_(rs)
-        xhat = (y - mu[:, None]) * rs[:, None]
-        xn.copy_((xhat if gamma is None else xhat * gamma + beta).to(xn.dtype))
 
     # LayerNorm as a raw operand + the fused MLP forward (include/mbx.h; the no-grad path) ---------------------
     fuse_mlp = True           # tests switch it off to exercise the unfused no-grad sequencing
@@ -315,19 +297,6 @@ class MockOps:
             mu_y = out.mean(-1)
             mean.copy_(mu_y)
             rstd.copy_(torch.rsqrt(((out - mu_y[:, None]) ** 2).mean(-1) + eps))
-
-    def gemm_nt_resid_t(self, a_t, w_t, bias, resid, y, y_t):
-        """MBX_EPI_RESID + y_t = T(y)."""
-        self._log('gemm_nt.resid_t')
-        out = resid + a_t.float() @ w_t.float().t() + (bias if bias is not None else 0.0)
-        y.copy_(out)
-        y_t.copy_(out.to(y_t.dtype))
-
-    def gemm_nt_rawln(self, a_t, w_t, bias, rsum, mean, rstd, out_t):
-        """out_t = rstd (a . w^T - mean rsum) + bias: the Linear behind a LayerNorm whose input rows arrive raw."""
-        self._log('gemm_nt.rawln')
-        acc = a_t.float() @ w_t.float().t()
-        out_t.copy_((rstd[:, None] * (acc - mean[:, None] * rsum) + bias).to(out_t.dtype))
 
     def gelu_fwd(self, u, g):
         self._log('gelu_fwd')

@@ -32,7 +32,7 @@ def _dump_report():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, 'fold_parity.json'), 'w') as f:
-        json.dump({k: v for k, v in REPORT.items() if 'fold' in k or 'stats' in k or 'lnbwd' in k or 'plain' in k or 'resid_ln' in k}, f, indent=1, sort_keys=True)
+        json.dump({k: v for k, v in REPORT.items() if 'fold' in k or 'stats' in k or 'lnbwd' in k or 'plain' in k}, f, indent=1, sort_keys=True)
 
 
 @pytest.mark.parametrize('bias', [True, False])
@@ -259,70 +259,3 @@ def test_folded_backward_equals_plain_backward(name):
     # GELU forms changed the realisation, this run had them at 0.052 (folded) against 0.021 (plain)
     bad = {n: (f['per'][n], p['per'][n]) for n in f['per'] if f['per'][n] > max(2 * p['per'][n] + 0.01, 0.08)}
     assert not bad, bad
-
-
-# ---------------------------------------------------------------------------------------------- residual GEMM + next LayerNorm
-def test_workgroups_with_equal_blockidx_mod_8_share_an_xcd(ops, monkeypatch):
-    """The rule `gemm_nt_resid_ln` relies on (and re-checks in the kernel): probed directly, on two grid sizes, and through the
-    provider's own switch -- with MBX_RESID_LN=1 the fused path must come ON on an MI355X, otherwise the model test below would
-    compare the fallback with itself."""
-    monkeypatch.setenv('MBX_RESID_LN', '1')
-    for nb in (8 * 31, 8 * 517 + 5):
-        out = torch.full((nb,), -1, dtype=torch.int32, device=DEV)
-        ops._ck(ops.lib.mbx_xcc_probe(out.data_ptr(), nb, torch.cuda.current_stream().cuda_stream))
-        ids = out.cpu()
-        assert int(ids.min()) >= 0 and int(ids.max()) < 8
-        for c in range(8):
-            assert len(set(ids[torch.arange(nb) % 8 == c].tolist())) == 1, f'class {c} of {nb} blocks spans XCDs'
-    REPORT['resid_ln.xcc_of_class'] = [int(ids[c]) for c in range(8)]
-    assert ops.can_fuse_resid_ln(BF, 512)
-
-
-@pytest.mark.parametrize('affine', [False, True])
-@pytest.mark.parametrize('M,N,K', [(264384, 512, 512), (264384, 512, 1024), (4131, 512, 512), (1000, 256, 128), (777, 1024, 64), (256, 512, 64), (5, 256, 64)])
-def test_gemm_nt_resid_ln_is_the_unfused_pair_bit_for_bit(ops, M, N, K, affine):
-    """y, xn, mean, rstd of the fused launch against mbx_gemm_nt(RESID) + mbx_layernorm_fwd: the same arithmetic on the same
-    values, so EQUAL, at the bench shape (1033 row blocks x 4 column tiles racing for 'last'), ragged M, one row block, every N the
-    entry accepts; three launches in a row (the counters must come back to zero)."""
-    from motionbert_amd.engine import EPI_RESID
-    a, w, b = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, scale=0.05, dtype=BF), rnd(N, seed=3)
-    resid = rnd(M, N, seed=4)
-    g, bt = (1.0 + 0.3 * rnd(N, seed=5), 0.2 * rnd(N, seed=6)) if affine else (None, None)
-    y0, xn0, mu0, rs0 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
-    ops.gemm_nt(a, w, b, EPI_RESID, resid=resid, out_f=y0)
-    ops.layernorm_fwd(y0, g, bt, 1e-6, xn0, mu0, rs0)
-    for it in range(3):
-        y, xn = torch.full((M, N), float('nan'), device=DEV), torch.full((M, N), float('nan'), device=DEV, dtype=BF)
-        mu, rs = torch.full((M,), float('nan'), device=DEV), torch.full((M,), float('nan'), device=DEV)
-        ops.gemm_nt_resid_ln(a, w, b, resid, y, g, bt, 1e-6, xn, mu, rs)
-        torch.cuda.synchronize()
-        tag = f'resid_ln.M{M}.N{N}.K{K}.{"affine" if affine else "plain"}'
-        assert torch.equal(y, y0), f'{tag}: y differs (launch {it})'
-        assert torch.equal(mu, mu0) and torch.equal(rs, rs0), f'{tag}: statistics differ (launch {it})'
-        assert torch.equal(xn, xn0), f'{tag}: normalised rows differ (launch {it}): {int((xn != xn0).any(-1).sum())} rows'
-    REPORT[tag] = 0.0
-    with pytest.raises(RuntimeError, match='alias'):
-        ops.gemm_nt_resid_ln(a, w, b, resid, resid, g, bt, 1e-6, xn, mu, rs)
-
-
-@pytest.mark.parametrize('name', ['lite_2x81', 'full_1x243'])
-def test_model_with_and_without_the_fused_layernorm_is_identical(name, monkeypatch):
-    """Whole bf16 model, forward + backward, MBX_RESID_LN=1 against =0: outputs and every gradient EQUAL (the fused launch changes
-    who computes the LayerNorm, not what is computed)."""
-    from tests.helpers import trained_like
-    z, cfg = load_golden(name)
-    res = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('MBX_RESID_LN', flag)
-        model = build_model(cfg, seed=0)
-        if int(z['trained_seed']) >= 0:
-            trained_like(model, int(z['trained_seed']))
-        model = model.to(DEV)
-        model.precision = 'bf16'
-        x = torch.from_numpy(z['x']).to(DEV).requires_grad_(True)
-        out = model(x)
-        (out * torch.from_numpy(z['cot']).to(DEV)).sum().backward()
-        res[flag] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters()})
-    assert torch.equal(res['1'][0], res['0'][0]) and torch.equal(res['1'][1], res['0'][1])
-    diff = [n for n in res['1'][2] if not torch.equal(res['1'][2][n], res['0'][2][n])]
-    assert not diff, diff

@@ -1,7 +1,7 @@
 """The no-grad path's kernels on a real MI355X against their torch restatement (oracle/torch_ops.MockOps, run on the GPU):
 the fused MLP forward (mbx_mlp_fused_fwd: LayerNorm'd or raw operand -> fc1 -> GELU -> fc2 -> + residual, reference
-lib/model/DSTformer.py:79-85 inside Block.forward :241-249), the residual GEMM that also leaves bf16(y) (mbx_gemm_nt_resid_t) and
-the Linear that applies the LayerNorm row constants in its epilogue (mbx_gemm_nt_rawln).
+lib/model/DSTformer.py:79-85 inside Block.forward :241-249) and the same kernel with the attention's proj + residual in front
+(mbx_proj_mlp_fused_fwd).
 
 Tolerances (relative L2): fp32 outputs of a bf16 GEMM chain 2e-5 where the operands are identical; the MLP's y goes through ONE
 bf16 rounding of the hidden in both implementations (a value that lands on the other side of a rounding boundary differs by
@@ -93,35 +93,6 @@ def test_mlp_fused_matches_unfused_kernels(ops):
     ops.gemm_nt(g, w2, b2, EPI_RESID, out_f=y2, resid=x)
     check('mlp_fused.vs_unfused.branch', y - x, y2 - x, 1e-3)
     check('mlp_fused.vs_unfused.y', y, y2, 2e-4)
-
-
-@pytest.mark.parametrize('M,N,K', [(306, 512, 512), (4131, 512, 512), (70227, 512, 1024), (2754, 256, 256)])
-def test_gemm_nt_resid_t(ops, M, N, K):
-    a, w, bias, resid = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, dtype=BF, scale=0.05), rnd(N, seed=3), rnd(M, N, seed=4)
-    y, y2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-    yt, yt2 = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
-    ops.gemm_nt_resid_t(a, w, bias, resid, y, yt)
-    MockOps().gemm_nt_resid_t(a, w, bias, resid, y2, yt2)
-    check(f'gemm_nt_resid_t.y.{M}x{N}x{K}', y, y2, 2e-5)
-    check(f'gemm_nt_resid_t.y_t.{M}x{N}x{K}', yt, yt2, 4e-3)
-    torch.cuda.synchronize()
-    assert torch.equal(yt, y.to(BF)), 'y_t must be the rounding of the y this launch wrote'
-
-
-@pytest.mark.parametrize('M,N,K', [(306, 768, 256), (4131, 1536, 512), (70227, 1536, 512), (300, 256, 512)])
-def test_gemm_nt_rawln(ops, M, N, K):
-    yrow = rnd(M, K, seed=1) * (0.5 + rnd(M, 1, seed=7).abs()) + 0.7 * rnd(M, 1, seed=8)
-    a, w, bias = yrow.to(BF), rnd(N, K, seed=2, dtype=BF, scale=0.05), rnd(N, seed=3)
-    rsum = w.float().sum(1)
-    mean = yrow.mean(-1)
-    rstd = torch.rsqrt(yrow.var(-1, unbiased=False) + 1e-6)
-    out, ref = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
-    ops.gemm_nt_rawln(a, w, bias, rsum, mean, rstd, out)
-    MockOps().gemm_nt_rawln(a, w, bias, rsum, mean, rstd, ref)
-    check(f'gemm_nt_rawln.{M}x{N}x{K}', out, ref, 4e-3)
-    # and it is the Linear behind the LayerNorm: against LayerNorm(y) . w^T + bias taken in fp32 from the fp32 rows
-    exact = ((yrow - mean[:, None]) * rstd[:, None]) @ w.float().t() + bias
-    check(f'gemm_nt_rawln.vs_layernorm.{M}x{N}x{K}', out, exact, 1e-2)
 
 
 @pytest.mark.parametrize('M,C,hidden', [(1000, 512, 1024), (128 * 3 + 5, 256, 1024), (4131, 512, 1024), (77, 512, 128), (2 * 243 * 17, 256, 1024),

@@ -22,19 +22,16 @@ def _load(model, z):
     assert not missing.missing_keys and not missing.unexpected_keys
 
 
-@pytest.mark.parametrize('resid_ln', [True, False])
 @pytest.mark.parametrize('fold', [True, False])
 @pytest.mark.parametrize('name', ['tiny_default', 'tiny_trained'])
-def test_engine_fp32_matches_reference_gradients(name, fold, resid_ln):
+def test_engine_fp32_matches_reference_gradients(name, fold):
     """Both backward formulations against the reference's autograd gradients: fold=True is the LayerNorm-folded sequencing
-    (LayerNorm backward as the dX GEMM's epilogue from the producers' row dots; the product's bf16 path), fold=False the plain one.
-    resid_ln: the residual GEMM also writes the LayerNorm output of the sub-layer that reads it (3 of a Block's 4 norms)."""
+    (LayerNorm backward as the dX GEMM's epilogue from the producers' row dots; the product's bf16 path), fold=False the plain one."""
     z, cfg = load_golden(name)
     model = build_model(cfg)
     _load(model, z)
     model.precision, model.fold_ln = 'fp32', fold
     ops = MockOps()
-    ops.fuse_resid_ln = resid_ln
     x = torch.from_numpy(z['x']).requires_grad_(True)
     out = M.run(ops, model, x)
     assert out.shape == z['out'].shape and out.dtype == torch.float32
@@ -56,9 +53,8 @@ def test_engine_fp32_matches_reference_gradients(name, fold, resid_ln):
     assert n_lnbwd == ops.calls.count('unfold_norm_grads') == ops.calls.count('lnbwd_rowc') == (8 * depth if fold else 0)
     # gradient stream in the operand type: the three inner LayerNorm-backward GEMMs of every Block write no fp32 dx
     assert ops.calls.count('gemm_nt.lnbwd.stream') == (6 * depth if fold else 0)
-    # forward: 8 residual GEMMs per level; 6 of them (all but each Block's last) carry the next LayerNorm
-    assert ops.calls.count('gemm_nt.resid_ln') == (6 * depth if resid_ln else 0)
-    assert ops.calls.count('gemm_nt.resid_ln') + ops.calls.count('gemm_nt.2') == 8 * depth
+    # forward: 8 residual GEMMs per level
+    assert ops.calls.count('gemm_nt.2') == 8 * depth
 
 
 def test_engine_representation_path(golden_dir):

@@ -101,29 +101,6 @@ def main():
         res['nt.' + name] = dict(ms=round(ms, 4), tflops=round(tf, 1), err=err)
         print(f'nt {name:8s} M={M} N={N} K={K}: {ms:8.4f} ms  {tf:7.1f} TF/s  err={err}', flush=True)
         del a, w, xhat, dres, rowc, dx, dx_t
-    # residual GEMM + the next LayerNorm in one launch (round 3), and the stand-alone LayerNorm it replaces
-    for name, N, K in [('proj_ln', 512, 512), ('fc2_ln', 512, 1024), ('ln_only', 512, 0)]:
-        if only and name not in only:
-            continue
-        y, xn, mu, rs = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev, dtype=bf), torch.empty(M, device=dev), torch.empty(M, device=dev)
-        resid = rnd(M, N)
-        if K == 0:
-            ms = timeit(lambda: ops.layernorm_fwd(resid, None, None, 1e-6, xn, mu, rs), args.iters)
-            print(f'   {name:8s} M={M} N={N}: {ms:8.4f} ms', flush=True)
-            res['ln.' + name] = dict(ms=round(ms, 4))
-            continue
-        a, w, bias = rnd(M, K).to(bf), (rnd(N, K) * 0.05).to(bf), rnd(N)
-        ms = timeit(lambda: ops.gemm_nt_resid_ln(a, w, bias, resid, y, None, None, 1e-6, xn, mu, rs), args.iters)
-        tf = 2.0 * M * N * K / ms / 1e9
-        err = None
-        if args.check:
-            rows = torch.randint(0, M, (512,), generator=g).to(dev)
-            ref = a[rows].float() @ w.float().t() + bias + resid[rows]
-            refn = torch.nn.functional.layer_norm(ref, (N,), eps=1e-6)
-            err = max(float((y[rows] - ref).norm() / ref.norm()), float((xn[rows].float() - refn).norm() / refn.norm()))
-        res['nt.' + name] = dict(ms=round(ms, 4), tflops=round(tf, 1), err=err)
-        print(f'nt {name:8s} M={M} N={N} K={K}: {ms:8.4f} ms  {tf:7.1f} TF/s  err={err}', flush=True)
-        del a, w, y, xn, resid
     tn = [('dW_qkv', 1536, 512), ('dW_proj', 512, 512), ('dW_fc1', 1024, 512), ('dW_fc2', 512, 1024)]
     for name, N, K in tn:
         if only and name not in only:

@@ -30,7 +30,6 @@ BF = torch.bfloat16
 
 
 def raw_training(ops):
-    ops.fuse_resid_ln = False          # every LayerNorm through layernorm_fwd, where the raw rows are recorded
     raw = []                           # the xhat tensors the engine passes around carry their raw rows as an attribute: (bf16(y), mean, rstd)
     p_ln, p_nt, p_tn, p_lnb = MockOps.layernorm_fwd, MockOps.gemm_nt, MockOps.gemm_tn, MockOps.gemm_nt_lnbwd
 

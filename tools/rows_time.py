@@ -44,12 +44,14 @@ for name, N, K, ln in (('qkv', 1536, 512, False), ('qkv raw-LN', 1536, 512, True
         rstd = torch.rsqrt(var + 1e-6)
         fn = lambda: ops.rows_gemm_nk_ln(x, packed, bias, rsum, 1e-6, out)
 
-        def old():
-            ops.layernorm_fwd(x, None, None, 1e-6, xn_t=xn, mean=mu, rstd=rs) if False else None
-            ops.gemm_nt_rawln(a, w, bias, rsum, mean, rstd, ref_out)
+        xhat, mu_, rs_ = torch.empty(M, K, device=dev, dtype=BF), torch.empty(M, device=dev), torch.empty(M, device=dev)
+
+        def old():      # what the row kernel replaces: a LayerNorm pass + the tile GEMM on its output (unit gamma: the folded form)
+            ops.layernorm_fwd(x, None, None, 1e-6, xhat, mu_, rs_)
+            ops.gemm_nt(xhat, w, bias, 0, out_t=ref_out)
     elif ln:
         fn = lambda: ops.rows_gemm_nk(a, packed, bias, out, rsum, mean, rstd)
-        old = lambda: ops.gemm_nt_rawln(a, w, bias, rsum, mean, rstd, ref_out)
+        old = lambda: ops.gemm_nt(a, w, bias, 0, out_t=ref_out)      # (the tile kernel has no raw-operand epilogue any more: plain product for the time)
     else:
         fn = lambda: ops.rows_gemm_nk(a, packed, bias, out)
         old = lambda: ops.gemm_nt(a, w, bias, 0, out_t=ref_out)
