@@ -1,0 +1,152 @@
+// Round 5 ("measure -- do not rule out on paper -- a 2-waves-per-SIMD split" of the fused MLP).
+// The fused MLP's chunk loop in SKELETON form, in two shapes, with the real kernel's memory behaviour (a 2.5-MiB packed weight stream
+// that every CU re-reads, through a 4 x 32 KiB LDS ring filled by LDS-DMA, one barrier per 32-slot stage) and nothing else:
+//   shape 0 (the product):  4 waves, one per SIMD; a wave owns 32 rows: v_mfma_f32_32x32x16_bf16 (32 cycles), one 1-KiB weight
+//                           fragment per MFMA from LDS, 8 LDS-DMA pieces per wave and stage;
+//   shape 1 (the candidate): 8 waves, two per SIMD; a wave owns 16 rows: v_mfma_f32_16x16x32_bf16 (16 cycles), one 1-KiB fragment
+//                           per MFMA -- twice the LDS read traffic per flop (256 B/clk per CU at the full matrix rate = the LDS's
+//                           ds_read_b128 peak) --, 4 LDS-DMA pieces per wave and stage, half the accumulators per wave.
+// FILL = VALU operations per slot beside the MFMA (the GELU of the real loop: ~6 per slot and wave in shape 0 on half of the stages,
+// i.e. ~3 on average; shape 1 has half the rows per wave: ~1.5).  Reported: us per stage of 32 slots (both shapes do the same
+// matrix work per stage and CU: 4 x 32 MFMAs of 32 cycles = 8 x 32 of 16), and the MFMA rate of the whole chip.
+//     hipcc --offload-arch=gfx950 -O3 tools/probes/mlp_shape_probe.hip -o tools/probes/mlp_shape_probe && tools/probes/mlp_shape_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+static constexpr int STAGE = 32 * 1024, RING = 4 * STAGE, NSTREAM = 80;   // 80 stages = 2.5 MiB: proj + fc1 + fc2 of one tile
+
+__device__ __forceinline__ void glds16_s(const char* base, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ u32x4_t lds_read16(unsigned base, int imm) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(base + imm);
+}
+template <int N> __device__ __forceinline__ void vmwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+template <int SHAPE, int FILL, bool DMA>
+__global__ __launch_bounds__(SHAPE ? 512 : 256, 1) void loop_kernel(const char* __restrict__ wpk, float* __restrict__ sink, int tiles) {
+    constexpr int NW = SHAPE ? 8 : 4;            // waves per workgroup
+    constexpr int PPW = 32 / NW;                 // LDS-DMA pieces (1 KiB) per wave and stage
+    constexpr int PF = 5;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned fr = (unsigned)(uintptr_t)(const lds_void_t*)ring + lane * 16;
+    const unsigned wvo = wave * 1024 + lane * 16;
+    const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
+    // token operand: a few fragments of pseudo-random bf16 (registers only)
+    u32x4_t X[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) X[k][e] = 0x3f803f80u ^ ((uint32_t)(tid * 2654435761u + k * 40503u + e * 9973u) & 0x007f007fu);
+    f32x16_t accA[SHAPE ? 1 : 16];
+    f32x4_t accB[SHAPE ? 32 : 1];
+#pragma unroll
+    for (int t = 0; t < (SHAPE ? 1 : 16); ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accA[t][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < (SHAPE ? 32 : 1); ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accB[t][e] = 0.f;
+    float fv[4] = {1.0f + lane * 1e-3f, 0.5f, 0.25f, 0.125f};
+
+    // piece j (0 .. PPW - 1) of this wave in a stage: KiB number j * NW + wave
+    auto issue = [&](int q, int j) {
+        if (DMA) glds16_s(wpk + (size_t)(q % NSTREAM) * STAGE + (size_t)j * NW * 1024, wvo, dl + (q & 3) * STAGE + j * NW * 1024);
+    };
+    const int nstages = tiles * NSTREAM;
+    // preamble: stages 0, 1, 2 and the first quarter of stage 3 (the product's ring schedule)
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue(q, j);
+#pragma unroll
+    for (int j = 0; j < PPW / 4; ++j) issue(3, j);
+    vmwait<2 * PPW + PPW / 4>();
+    __syncthreads();
+    u32x4_t fb[8];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
+    for (int q = 0; q < nstages; ++q) {
+        unsigned st = fr + (q & 3) * STAGE, sn = fr + ((q + 1) & 3) * STAGE;
+        asm volatile("" : "+v"(st), "+v"(sn));
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k == 32 - PF) {      // stage q + 1 has landed (younger: stages q + 2, q + 3), everyone is done with stage q's buffer
+                vmwait<2 * PPW>();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fb[(k + PF) & 7] = k + PF < 32 ? lds_read16(st, (k + PF) * 1024) : lds_read16(sn, (k + PF - 32) * 1024);
+            if (SHAPE == 0) accA[k & 15] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[k & 7]), __builtin_bit_cast(bf16x8_t, X[k & 7]), accA[k & 15], 0, 0, 0);
+            else accB[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb[k & 7]), __builtin_bit_cast(bf16x8_t, X[k & 7]), accB[k], 0, 0, 0);
+            // the weight stream: pieces PPW/4 .. PPW-1 of stage q + 3 spread over slots < 24, the first PPW/4 of stage q + 4 behind the barrier
+            if (PPW == 8 && (k & 3) == 3) { if (k < 24) issue(q + 3, (k >> 2) + 2); else issue(q + 4, (k >> 2) - 6); }
+            if (PPW == 4 && (k & 7) == 7) { if (k < 24) issue(q + 3, (k >> 3) + 1); else issue(q + 4, 0); }
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) fv[f & 3] = fmaf(fv[f & 3], fv[(f + 1) & 3], 0.001f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = fv[0] + fv[1] + fv[2] + fv[3];
+#pragma unroll
+    for (int t = 0; t < (SHAPE ? 1 : 16); ++t) s += accA[t][0] + accA[t][15];
+#pragma unroll
+    for (int t = 0; t < (SHAPE ? 32 : 1); ++t) s += accB[t][0] + accB[t][3];
+    sink[blockIdx.x * blockDim.x + tid] = s;
+}
+
+template <int SHAPE, int FILL, bool DMA>
+static void run(const char* name, const char* wpk, float* sink, int tiles) {
+    auto k = loop_kernel<SHAPE, FILL, DMA>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, RING);
+    const int threads = SHAPE ? 512 : 256, blocks = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), RING, 0, wpk, sink, tiles);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), RING, 0, wpk, sink, tiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double stages = (double)tiles * NSTREAM;
+    const double flops = 256.0 * stages * 4 * 32 * (2.0 * 32 * 32 * 16);     // per CU and stage: 4 x 32 big MFMAs (or 8 x 32 halves)
+    printf("%-58s %7.3f us per stage   %6.0f TFLOP/s   (%s)\n", name, ms * 1e3 / stages, flops / ms / 1e9, hipGetErrorString(hipGetLastError()));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+}
+
+int main() {
+    const size_t nb = (size_t)NSTREAM * STAGE;
+    std::vector<uint16_t> h(nb / 2);
+    uint32_t r = 12345;
+    for (auto& v : h) { r = r * 1664525u + 1013904223u; v = (uint16_t)(0x3c00u | ((r >> 16) & 0x83ffu)); }      // bf16 values of magnitude ~0.01 .. 0.03, random signs
+    char* wpk;
+    float* sink;
+    hipMalloc(&wpk, nb);
+    hipMalloc(&sink, 256 * 512 * sizeof(float));
+    hipMemcpy(wpk, h.data(), nb, hipMemcpyHostToDevice);
+    const int tiles = 24;
+    printf("# fused-MLP loop skeleton, 256 workgroups (one per CU), %d tiles x %d stages of 32 MFMA slots; 0.52 us per stage = the matrix pipe at 1.96 GHz\n", tiles, NSTREAM);
+    run<0, 0, false>("shape 0 (4 waves, 32x32x16): MFMA + fragment reads", wpk, sink, tiles);
+    run<0, 0, true>("shape 0: + LDS-DMA weight stream", wpk, sink, tiles);
+    run<0, 3, true>("shape 0: + 3 VALU per slot", wpk, sink, tiles);
+    run<0, 6, true>("shape 0: + 6 VALU per slot", wpk, sink, tiles);
+    run<1, 0, false>("shape 1 (8 waves, 16x16x32): MFMA + fragment reads", wpk, sink, tiles);
+    run<1, 0, true>("shape 1: + LDS-DMA weight stream", wpk, sink, tiles);
+    run<1, 2, true>("shape 1: + 2 VALU per slot", wpk, sink, tiles);
+    run<1, 3, true>("shape 1: + 3 VALU per slot", wpk, sink, tiles);
+    return 0;
+}
