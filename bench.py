@@ -240,7 +240,7 @@ def _port_calibration():
         return None
 
 
-PMC_TABLE = next((p for p in (os.path.join(ROOT, 'profiles', f'r0{r}_pmc_bench.txt') for r in (4, 3, 2)) if os.path.exists(p)),
+PMC_TABLE = next((p for p in (os.path.join(ROOT, 'profiles', f'r0{r}_pmc_bench.txt') for r in (5, 4, 3, 2)) if os.path.exists(p)),
                  os.path.join(ROOT, 'profiles', 'r03_pmc_bench.txt'))
 HBM_PEAK_TBS, HBM_ACHIEVABLE_TBS = 8.0, 6.3      # MI355X_MICROARCH.md: spec / measured float4 copy
 
