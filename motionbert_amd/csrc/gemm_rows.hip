@@ -143,48 +143,21 @@ __global__ __launch_bounds__(256, 2) void rows_nk_kernel(const void* __restrict_
         // rounding error proportional to the spread of the row instead of to its magnitude (a row with a large common offset would
         // otherwise lose mean^2 / var of its precision).  The shift is the row's first element -- the s = 0 value of lane
         // (i, 0), handed to lane (i, 1) by one permlane swap -- so both halves, and the row constants below, use the same one.
+        // (Round 5, measured and dropped: these 2 K/16 loads per lane as asm statements in batches of eight with counted waits, 16 KiB
+        // per wave in flight instead of the ~4 loads the compiler keeps in flight here -- the prologue took the same 27 us of the tile's
+        // 128 (profiles/r05_rows_trace.txt): it is bound by the CU's miss bandwidth, which the other workgroup's weight stream shares.)
         const float* const ap = reinterpret_cast<const float*>(a) + (size_t)row * K + 8 * g;
         float xsh = 0.f, xs1 = 0.f, xs2 = 0.f;
-        // (round 5) the 2 K/16 loads of a lane go out in batches of eight, two batches ahead of the one being reduced and packed:
-        // 16 KiB per wave in flight.  Written as one loop over the k-steps the compiler kept ~4 loads in flight (every k-step uses
-        // its values at once, and all 64 do not fit the register file): ten dependent round trips to HBM, 26 of the tile's 133 us
-        // (profiles/r05_rows_trace.txt).
-        constexpr int BL = 4, NB = KS / BL;      // k-steps per batch, batches
-        // The loads and their waits are asm statements (the compiler's scheduler sinks plain loads back to their uses, one batch in
-        // flight at best); a batch's registers are in / out operands of its wait, so nothing can touch them before it.
-        typedef float rs_f4 __attribute__((ext_vector_type(4)));
-        rs_f4 rg_[3][BL][2];
-#define RS_XLD1(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst_) : "v"(ap), "n"(off_) : "memory")
-#define RS_XLOAD(b_)                                                                                                 \
-        _Pragma("unroll") for (int j_ = 0; j_ < BL; ++j_) {                                                          \
-            RS_XLD1(rg_[(b_) % 3][j_][0], 64 * ((b_) * BL + j_));                                                    \
-            RS_XLD1(rg_[(b_) % 3][j_][1], 64 * ((b_) * BL + j_) + 16);                                               \
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 lo = *reinterpret_cast<const float4*>(ap + 16 * s), hi = *reinterpret_cast<const float4*>(ap + 16 * s + 4);
+            if (s == 0) xsh = wave_lower_half(lo.x);
+            const float d[8] = {lo.x - xsh, lo.y - xsh, lo.z - xsh, lo.w - xsh, hi.x - xsh, hi.y - xsh, hi.z - xsh, hi.w - xsh};
+            xs1 += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xs2 = fmaf(d[e], d[e], xs2);
+            X[s] = u32x4_t{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3]), pack_bf2(d[4], d[5]), pack_bf2(d[6], d[7])};
         }
-#define RS_XWAIT(b_, n_) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(rg_[(b_) % 3][0][0]), "+v"(rg_[(b_) % 3][0][1]), "+v"(rg_[(b_) % 3][1][0]),     \
-                                      "+v"(rg_[(b_) % 3][1][1]), "+v"(rg_[(b_) % 3][2][0]), "+v"(rg_[(b_) % 3][2][1]), "+v"(rg_[(b_) % 3][3][0]), \
-                                      "+v"(rg_[(b_) % 3][3][1]) : "n"(n_) : "memory")
-        static_assert(BL == 4, "RS_XWAIT names the eight registers of a batch");
-        RS_XLOAD(0)
-        RS_XLOAD(1)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (b + 2 < NB) { RS_XLOAD(b + 2) }
-            // batch b has landed when at most the loads issued after it are outstanding: two batches, one, none
-            if (b + 2 < NB) { RS_XWAIT(b, 4 * BL); } else if (b + 1 < NB) { RS_XWAIT(b, 2 * BL); } else { RS_XWAIT(b, 0); }
-            if (b == 0) xsh = wave_lower_half(rg_[0][0][0][0]);
-#pragma unroll
-            for (int j = 0; j < BL; ++j) {
-                const rs_f4 lo = rg_[b % 3][j][0], hi = rg_[b % 3][j][1];
-                const float d[8] = {lo[0] - xsh, lo[1] - xsh, lo[2] - xsh, lo[3] - xsh, hi[0] - xsh, hi[1] - xsh, hi[2] - xsh, hi[3] - xsh};
-                xs1 += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xs2 = fmaf(d[e], d[e], xs2);
-                X[b * BL + j] = u32x4_t{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3]), pack_bf2(d[4], d[5]), pack_bf2(d[6], d[7])};
-            }
-        }
-#undef RS_XLOAD
-#undef RS_XLD1
-#undef RS_XWAIT
         constexpr float nh = (float)(K / 2);
         const float mean_h = xsh + xs1 / nh, m2_h = xs2 - xs1 * xs1 / nh;
         const float mean_o = wave_halves<WaveAdd>(mean_h) - mean_h;
