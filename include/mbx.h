@@ -329,6 +329,19 @@ int mbx_embed_fwd_tta(const float* x, const int* perm, const float* w, const flo
                       float* h, int B, int T, int J, int Din, int C, void* stream);
 int mbx_flip_average(const float* out2, const int* perm, float* out, int B, int T, int J, int D, void* stream);
 
+/* ---- "N-resident" row-owner GEMM with the LayerNorm backward as its epilogue (bf16; csrc/gemm_rows_n.hip; round 5) ---------------------
+ * The input gradient of a folded (LayerNorm -> Linear) pair INSIDE a Block (DSTformer.py:241-249: norm1 -> attn.qkv :143, norm2 ->
+ * mlp.fc1 :80; backward by autograd in the reference) in one launch, without row dots from the producers of dY:
+ *     dxhat = dy . w^T   (dy bf16 [M,K], w bf16 [512,K] = mbx_fold_norm_weights' transposed folded weight, packed by mbx_rows_n_pack)
+ *     dx_t  = bf16( dres_t + rstd (dxhat - mean_k dxhat - xhat mean_k(dxhat xhat)) )          all [M,512]
+ * A workgroup owns 128 complete rows (256 accumulator registers per wave), so both row means come from the accumulators; xhat bf16
+ * [M,512] and rstd f32 [M] are what mbx_layernorm_fwd (gamma = NULL) left, dres_t / dx_t the gradient of the residual stream in the
+ * operand type (as mbx_gemm_nt_lnbwd_t with dx = NULL).  N must be 512; K % 256 == 0.  dx_t must not alias an input. */
+size_t mbx_rows_n_pack_bytes(int K);
+int mbx_rows_n_pack(const void* w, void* packed, int K, void* stream);
+int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* xhat, const float* rstd, const void* dres_t, void* dx_t, int M,
+                     int N, int K, void* stream);
+
 /* ---- measurement aid (bench.py `roofline.sustained_mfma_tflops`; not part of the model) --------------------------------------------
  * The bf16 MFMA rate the part sustains under its power cap with nothing but v_mfma_f32_32x32x16_bf16 in the loop (pseudo-random
  * operands; n_wg workgroups of 4 waves, `iters` x 16 MFMAs per wave).  ws: >= mbx_mfma_probe_ws(n_wg) bytes = a float sink

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libmbx.so')
-SOURCES = ['elementwise.hip', 'gemm.hip', 'gemm_pipe.hip', 'mlp_fused.hip', 'gemm_rows.hip', 'attention.hip', 'train_step.hip', 'augment.hip', 'probe.hip']
+SOURCES = ['elementwise.hip', 'gemm.hip', 'gemm_pipe.hip', 'mlp_fused.hip', 'gemm_rows.hip', 'gemm_rows_n.hip', 'attention.hip', 'train_step.hip', 'augment.hip', 'probe.hip']
 HEADERS = [os.path.join(CSRC, 'mbx_common.h'), os.path.join(CSRC, 'gelu_fast.h'), os.path.join(CSRC, 'lds_stream.h'), os.path.join(os.path.dirname(HERE), 'include', 'mbx.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 

@@ -1,0 +1,231 @@
+// "N-resident" row-owner GEMM with the LayerNorm backward as its epilogue (round 5): the input gradient of a folded
+// (LayerNorm -> Linear) pair INSIDE a Block (reference lib/model/DSTformer.py:241-249: norm1 -> attn.qkv :143, norm2 -> mlp.fc1 :80;
+// the backward of these lines is autograd's in the reference),
+//     dxhat = dY . W'                                   [M, 512] <- [M, K] x [K, 512],  K = 1536 (qkv) or 1024 (fc1)
+//     dx    = dres + rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))      (LayerNorm backward, gamma folded into W')
+// with dres and dx travelling as bf16 (the gradient residual stream of include/mbx.h "mbx_gemm_nt_lnbwd_t").
+//
+// Why another GEMM shape.  The 256 x 128 tile kernel (gemm_pipe.hip) runs this product in four column tiles per row block, so the two
+// row means of LayerNorm's backward had to come from the PRODUCERS of dY as row dots (round 3), and its N = 512 / long-K loop is the
+// one shape the vendor library beats by 20 % (profiles/r04_gemm_vs_blas.txt).  Here a workgroup = 4 waves owns 128 COMPLETE rows:
+// wave w keeps its 32 x 512 slice of dxhat in 256 accumulator registers (the fc2 half of the fused MLP, mlp_fused.hip), the weights
+// stream as packed 1-KiB MFMA fragments through the 4 x 32 KiB LDS ring, the wave's token fragments (16 bytes per lane and k-step:
+// row i, columns 16 s + 8 g of dY) are plain global loads issued four stages ahead, and the epilogue takes both row means from the
+// accumulators themselves -- no row dots from the attention-backward / GELU' kernels, no row-constant launch.
+// Skeleton measured first (tools/probes/mlp_shape_probe.hip, profiles/r05_mlp_shape_probe.txt): the bare product 0.40 ms at K = 1536 and
+// 0.27 ms at K = 1024 (the tile kernel: 0.51 / 0.38 plain, 0.61 / 0.41 with this epilogue; the vendor's plain product 0.40 / 0.31).
+//
+// vmcnt discipline (loads and LDS-DMA share one in-order counter): stage q issues, in slot order, the weight pieces 2..7 of stage q + 3
+// (slots 3..23), the two token fragments of stage q + 4 (slots 25, 29) and pieces 0, 1 of stage q + 4 (slots 27, 31).  At the barrier of
+// stage q (slot 27) "stage q + 1 has landed" leaves the 21 younger operations in flight: (q-2: T P T P) + (q-1: 6 P, T, P, T, P) +
+// (q: 6 P, T); everything older -- in particular the tokens of stage q + 1, issued in stage q - 3 -- has landed with it, so the token
+// registers need no wait of their own.  The preamble issues the first eight tokens BEFORE the ring instead of interleaved: the first two
+// stages of a trip wait for 17 / 19 instead of 21 (a slightly stronger wait on later trips, no branch).
+#include "mbx_common.h"
+#include "lds_stream.h"
+
+static constexpr int RN_BM = 128;              // token rows per workgroup (4 waves x 32)
+static constexpr int RN_N = 512;               // output columns = the accumulators of a wave (16 tiles of 32)
+static constexpr int RN_STAGE = 32 * 1024;     // one ring stage = 32 fragments = 2 k-steps x 16 column tiles
+static constexpr int RN_RING = 4 * RN_STAGE;
+
+// packed stream: fragment (kk, nt) at index kk * 16 + nt; lane (i, g) owns bytes [16 l, 16 l + 16) = w[32 nt + i][16 kk + 8 g + t],
+// t = 0..7, w = the [512, K] row-major operand of mbx_gemm_nt (for dX: the transposed folded weight W'^T)
+__global__ __launch_bounds__(256) void rows_n_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int K) {
+    const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (frag >= (K / 16) * 16) return;
+    const int kk = frag >> 4, nt = frag & 15, i = lane & 31, g = lane >> 5;
+    *reinterpret_cast<uint4*>(out + (size_t)frag * 512 + lane * 8) = *reinterpret_cast<const uint4*>(w + (size_t)(32 * nt + i) * K + 16 * kk + 8 * g);
+}
+
+template <int N> __device__ __forceinline__ void rn_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+__global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __restrict__ dy, const char* __restrict__ wpk,
+                                                             const bf16_t* __restrict__ xhat, const float* __restrict__ rstd,
+                                                             const bf16_t* __restrict__ dres_t, bf16_t* __restrict__ dx_t, int M, int K) {
+    constexpr int PF = 5;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    const int mw = blockIdx.x * RN_BM + 32 * wave;
+    const unsigned fr = (unsigned)(uintptr_t)(const lds_void_t*)ring + lane * 16;
+    const unsigned wvo = wave * 1024 + lane * 16;
+    const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
+    const int nstages = K / 32;
+    // stage q of the stream (past the end: a harmless re-read of the last stage into a slot nobody reads again)
+#define RN_ISSUE(q_, j_) glds16_s(wpk + (size_t)min((q_), nstages - 1) * RN_STAGE + (j_) * 4096, wvo, dl + ((q_) & 3) * RN_STAGE + (j_) * 4096)
+    // token fragments: lane (i, g) = 16 bytes of row i at k = 16 s + 8 g; rows past M repeat row M - 1 (their results are never stored)
+    const char* ap = reinterpret_cast<const char*>(dy + (size_t)min(mw + i, M - 1) * K + 8 * g);
+    u32x4_t tok[16];                               // fragment s lives in tok[s & 15]
+#define RN_TOK(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst_) : "v"(ap), "n"(off_) : "memory")
+#define RN_TOKN(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst_) : "v"(apn), "n"(off_) : "memory")
+    RN_TOK(tok[0], 0); RN_TOK(tok[1], 32); RN_TOK(tok[2], 64); RN_TOK(tok[3], 96);
+    RN_TOK(tok[4], 128); RN_TOK(tok[5], 160); RN_TOK(tok[6], 192); RN_TOK(tok[7], 224);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) RN_ISSUE(q, j);
+    RN_ISSUE(3, 0);
+    RN_ISSUE(3, 1);
+    f32x16_t acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        asm volatile("" : "+a"(acc[t]));            // zeroed in the accumulator file while the first loads are in flight
+    }
+    rn_vmwait<18>();                               // stage 0 (and, older, the first tokens) has landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4_t fb[8];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
+    // ---- the product: trips of 8 stages = 16 k-steps (the token ring's indices are then static); K % 256 == 0
+    for (int q0 = 0; q0 < nstages; q0 += 8) {
+        const char* const apn = q0 + 8 < nstages ? ap + 512 : ap;      // where the tokens of the next trip's first half are
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u;
+            unsigned st = fr + (u & 3) * RN_STAGE, sn = fr + ((u + 1) & 3) * RN_STAGE;
+            asm volatile("" : "+v"(st), "+v"(sn));
+            const char* const n3 = wpk + (size_t)min(q + 3, nstages - 1) * RN_STAGE;
+            const char* const n4 = wpk + (size_t)min(q + 4, nstages - 1) * RN_STAGE;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                if (k == 32 - PF) {
+                    if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else rn_vmwait<21>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                fb[(k + PF) & 7] = k + PF < 32 ? lds_read16(st, (k + PF) * 1024) : lds_read16(sn, (k + PF - 32) * 1024);
+                // slot k: k-step (k >> 4) of the stage, column tile k & 15
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[k & 15]) : "v"(fb[k & 7]), "v"(tok[(2 * u + (k >> 4)) & 15]));
+                if ((k & 3) == 3) {
+                    if (k < 24) glds16_s(n3 + ((k >> 2) + 2) * 4096, wvo, dl + ((u + 3) & 3) * RN_STAGE + ((k >> 2) + 2) * 4096);
+                    else glds16_s(n4 + ((k >> 2) - 6) * 4096, wvo, dl + ((u + 4) & 3) * RN_STAGE + ((k >> 2) - 6) * 4096);
+                }
+                // tokens of stage q + 4: this trip's second half, or the next trip's first half (in the last trip: this trip's first half
+                // again -- loaded for nothing, but never outside the row)
+                if (k == 25) { if (u < 4) RN_TOK(tok[(2 * (u + 4)) & 15], 32 * (2 * (u + 4))); else RN_TOKN(tok[(2 * (u + 4)) & 15], 32 * (2 * (u - 4))); }
+                if (k == 29) { if (u < 4) RN_TOK(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u + 4) + 1)); else RN_TOKN(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u - 4) + 1)); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        ap += 512;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the re-read tail stages and the over-read tokens have landed
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring: it becomes four 8-KiB buffers per wave
+#pragma unroll
+    for (int t = 0; t < 16; ++t) MFMA_PAD_A(acc[t]);
+
+    // ---- epilogue.  Quarter j of a row (columns [128 j, 128 j + 128), 256 bytes of bf16) of xhat / dres arrives in one of the wave's four
+    // 8-KiB buffers by LDS-DMA: one instruction = 4 rows x 256 bytes; 16-byte piece p of row r at slot p ^ (r & 15) (applied to the
+    // source address).  A lane reads its accumulator positions (row i, columns 32 ntl + 8 qq + 4 g + e) as 8-byte halves of pieces.
+    // Pass 1: the four quarters of xhat -> the two row means.  Pass 2, per quarter (double-buffered in buffer pairs): xhat again
+    // (L2-hot: keeping it in registers instead costs 128 of them and spills) + dres -> dx, written over the dres it was made from,
+    // read back row-major and stored as whole 256-byte row segments.
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, i_e = lane_e & 31, g_e = lane_e >> 5;
+    char* const eb = ring + wave * 32768;
+    const int xr = lane_e >> 4, xp = lane_e & 15;
+    auto issue_q = [&](const bf16_t* src, int j, char* buf) {      // 8 instructions
+#pragma unroll
+        for (int r4 = 0; r4 < 8; ++r4) {
+            const int rl = 4 * r4 + xr;
+            GLDS16(src + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp ^ (rl & 15)) << 3), buf + r4 * 1024);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_q(xhat, j, eb + j * 8192);
+    const float rs = rstd[min(mw + i_e, M - 1)];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+        const f32x16_t t = acc[nt];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const uint2 xv = *reinterpret_cast<const uint2*>(eb + (nt >> 2) * 8192 + i_e * 256 + ((((nt & 3) * 4 + qq) ^ (i_e & 15)) << 4) + 8 * g_e);
+            const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
+            const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
+            c1 += (t[4 * qq] + t[4 * qq + 1]) + (t[4 * qq + 2] + t[4 * qq + 3]);
+            c2 = fmaf(t[4 * qq], x0, fmaf(t[4 * qq + 1], x1, fmaf(t[4 * qq + 2], x2, fmaf(t[4 * qq + 3], x3, c2))));
+        }
+        __builtin_amdgcn_sched_barrier(0);                            // one tile's 16 registers at a time out of the accumulator file
+    }
+    c1 = wave_halves<WaveAdd>(c1) * (1.0f / (float)RN_N);             // the two halves of row i: lanes i and i + 32
+    c2 = wave_halves<WaveAdd>(c2) * (1.0f / (float)RN_N);
+    const float k1 = -rs * c1, k2 = -rs * c2;                         // dx = dres + rs t + k1 + k2 xhat
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the buffers have been read out
+    // quarter j lives in the buffer pair 2 (j & 1): xhat in the first, dres (then dx) in the second
+    issue_q(xhat, 0, eb); issue_q(dres_t, 0, eb + 8192);
+    issue_q(xhat, 1, eb + 16384); issue_q(dres_t, 1, eb + 24576);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // vector memory operations younger than quarter j's requests: quarter j + 1's (16) and the stores of quarter j - 1 (8) in between
+        if (j == 0) rn_vmwait<16>(); else if (j < 3) rn_vmwait<24>(); else rn_vmwait<8>();
+        char* const bx = eb + (j & 1) * 16384;
+        char* const bd = bx + 8192;
+#pragma unroll
+        for (int ntl = 0; ntl < 4; ++ntl) {
+            const f32x16_t t = acc[4 * j + ntl];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int off = i_e * 256 + (((ntl * 4 + qq) ^ (i_e & 15)) << 4) + 8 * g_e;
+                const uint2 xv = *reinterpret_cast<const uint2*>(bx + off);
+                uint2* const p = reinterpret_cast<uint2*>(bd + off);
+                const uint2 dv = *p;
+                const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
+                const float d2 = __uint_as_float(dv.y << 16), d3 = __uint_as_float(dv.y & 0xffff0000u);
+                const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
+                const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
+                const float o0 = fmaf(rs, t[4 * qq], fmaf(k2, x0, d0 + k1)), o1 = fmaf(rs, t[4 * qq + 1], fmaf(k2, x1, d1 + k1));
+                const float o2 = fmaf(rs, t[4 * qq + 2], fmaf(k2, x2, d2 + k1)), o3 = fmaf(rs, t[4 * qq + 3], fmaf(k2, x3, d3 + k1));
+                *p = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));  // over the dres value it was made from: same lane, same place
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the quarter leaves row-major: one instruction = 4 rows x 256 bytes (the lanes that wrote a row are other lanes of THIS wave,
+        // and LDS executes a wave's instructions in order; the asm statement keeps the compiler from moving the reads above the writes)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r4 = 0; r4 < 8; ++r4) {
+            const int rl = 4 * r4 + xr;
+            const uint4 v = *reinterpret_cast<const uint4*>(bd + r4 * 1024 + lane_e * 16);
+            // rows past M were computed from row M - 1's inputs (every load is clamped) and are stored onto row M - 1: identical bytes,
+            // and every wave issues the same number of vector memory instructions -- the counted waits above depend on it
+            *reinterpret_cast<uint4*>(dx_t + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp ^ (rl & 15)) << 3)) = v;
+        }
+        if (j + 2 < 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the pair has been read out
+            issue_q(xhat, j + 2, bx);
+            issue_q(dres_t, j + 2, bd);
+        }
+    }
+}
+
+// ---- C ABI -------------------------------------------------------------------------------------------------------------------
+extern "C" size_t mbx_rows_n_pack_bytes(int K) { return (size_t)RN_N * K * sizeof(bf16_t); }
+
+extern "C" int mbx_rows_n_pack(const void* w, void* packed, int K, void* stream) {
+    MBX_CHECK_ARG(w && packed, "rows_n_pack: null pointer");
+    MBX_CHECK_ARG(K > 0 && K % 256 == 0, "rows_n_pack: K=%d (%% 256)", K);
+    const int nfrag = (K / 16) * 16;
+    hipLaunchKernelGGL(rows_n_pack_kernel, dim3((nfrag + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)packed, K);
+    MBX_LAUNCH_CHECK("rows_n_pack");
+    return 0;
+}
+
+extern "C" int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* xhat, const float* rstd, const void* dres_t, void* dx_t,
+                                int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(dy && packed && xhat && rstd && dres_t && dx_t, "rows_lnbwd_t: null pointer");
+    MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 256 && K % 256 == 0, "rows_lnbwd_t: bad shape M=%d N=%d (512) K=%d (%% 256)", M, N, K);
+    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_lnbwd_kernel), RN_RING, "rows_lnbwd_t")) return 1;
+    hipLaunchKernelGGL(rows_n_lnbwd_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const char*)packed, (const bf16_t*)xhat, rstd, (const bf16_t*)dres_t, (bf16_t*)dx_t, M, K);
+    MBX_LAUNCH_CHECK("rows_lnbwd_t");
+    return 0;
+}

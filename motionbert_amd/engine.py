@@ -166,6 +166,12 @@ class Engine:
         self.gstream = False      # decided per backward (the folded sequencing only)
         self.Bf: Dict[str, torch.Tensor] = {}
         self.Rs: Dict[str, torch.Tensor] = {}
+        # Round 5: inside a Block (bf16 gradient stream in and out, no second summand) the folded LayerNorm backward runs as the
+        # epilogue of a row-owner GEMM that takes both row means from its own accumulators (mbx_rows_lnbwd_t): the producers of dY --
+        # attention backward, the GELU' GEMM -- run WITHOUT their row dots there, and no row-constant launch is needed.  The first
+        # sub-layer of a Block (fp32 out, the other block's gradient added) keeps the tile kernel.  MBX_ROWS_LNBWD=0: the A/B switch.
+        self.rows_lnbwd = (os.environ.get('MBX_ROWS_LNBWD', '1') == '1' and bool(getattr(ops, 'can_rows_lnbwd', lambda *_: False)(tdtype, cfg)))
+        self.Pn: Dict[str, torch.Tensor] = {}       # transposed folded weights in the fragment order of mbx_rows_lnbwd_t
         # no-grad sequencing of a Block (decided per forward): raw-operand LayerNorm + fused MLP, see the module docstring
         self.rawln = False
         self.rawln_allowed = os.environ.get('MBX_RAWLN', '1') == '1'      # A/B switch: 0 = the training sequencing without saves
@@ -292,6 +298,8 @@ class Engine:
             fn, ft, self.Bf, self.Rs = ops.fold_norm_weights(P, pairs, need_grad, self.T)
             self.Wn.update(fn)
             self.Wt.update(ft)
+            if need_grad and self.rows_lnbwd and self.gstream_allowed:
+                self.Pn = {lin: ops.rows_n_pack(ft[lin]) for lin, _ in pairs}
             if self.rawln:
                 for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')):
                     for i in range(cfg.depth):
@@ -630,6 +638,10 @@ class Engine:
         dqkv = self._t(M, 3 * C) if self.fold else self._op(M, 3 * C)     # (bf16x3: the attention backward writes the operand planes itself)
         if self.fold:
             lin = f'{pre}.{attn}.qkv'
+            if self._rows_tail_ok(lin, dy_t, extra, need_t):      # the consumer takes its row means itself: plain attention backward
+                ops.attn_bwd(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.B, self.Tlen, cfg.J, cfg.H, cfg.scale, mode)
+                del do
+                return self._fold_tail(dqkv, None, sv, lin, f'{pre}.{norm}', dy, dy_t, extra, need_t)
             part = self._f(2 * cfg.H, M, 2)       # block-major; per head: the q columns, the k + v columns
             ops.attn_bwd_stats(sv['qkv'], sv['o'], do, sv['lse'], dqkv, self.Bf[lin], self.Rs[lin], part, self.B, self.Tlen, cfg.J, cfg.H,
                                cfg.scale, mode)
@@ -653,6 +665,10 @@ class Engine:
                           dx, dx_t, G[f'{pre}.{norm}.weight'], G[f'{pre}.{norm}.bias'])
         return dx, dx_t
 
+    def _rows_tail_ok(self, lin, dy_t, extra, need_t) -> bool:
+        """The row-owner LayerNorm-backward GEMM serves a folded pair whose gradient arrives and leaves in the operand type only."""
+        return bool(self.rows_lnbwd and self.gstream and need_t and dy_t is not None and extra is None and lin in self.Pn)
+
     def _fold_tail(self, dY, part, sv, lin, norm, dy, dy_t, extra, need_t):
         """Folded (LayerNorm -> Linear) pair, backward from the Linear's output gradient dY and its row dots `part`: weight
         gradient, then dx = dy [+ extra] + LayerNorm'(dY . W') as the epilogue of the dX GEMM, then the parameter gradients of
@@ -660,8 +676,10 @@ class Engine:
         dy is read as dy_t and, inside a Block (need_t), only the T-typed dx is written: returns (None, dx_t)."""
         cfg, ops, P, G = self.cfg, self.ops, self.P, self.grads
         M, C = self.M, cfg.C
-        rowc = self._f(M, 4)
-        ops.lnbwd_rowc(part, sv['rstd'], rowc, C)
+        rows = part is None                # (round 5) row means taken by the dX kernel itself: no row dots, no row constants
+        if not rows:
+            rowc = self._f(M, 4)
+            ops.lnbwd_rowc(part, sv['rstd'], rowc, C)
         db = G.get(lin + '.bias')
         if db is None:                     # qkv_bias=False: the column sums of dY are still needed for d(beta)
             db = self._f(dY.shape[1])
@@ -670,6 +688,10 @@ class Engine:
         dres = dy_t if stream else dy
 
         def dx_gemm(extra):
+            if rows:
+                dx_t = self._t(M, C)
+                ops.rows_lnbwd_t(dY, self.Pn[lin], sv['xn'], sv['rstd'], dres, dx_t)
+                return None, dx_t
             dx = None if (stream and need_t) else self._f(M, C)
             dx_t = self._t(M, C) if need_t else None
             if callable(extra):      # dual-stream backward: the other block's input gradient, awaited only now
@@ -715,6 +737,9 @@ class Engine:
         del g
         if self.fold:
             lin = f'{pre}.{mlp}.fc1'
+            if self._rows_tail_ok(lin, dy_t, extra, need_t):      # the consumer takes its row means itself: plain GELU' epilogue
+                ops.gemm_nt(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], None, EPI_DGELU, out_t=du, aux_t=sv['u'])
+                return self._fold_tail(du, None, sv, lin, f'{pre}.{norm}', dy, dy_t, extra, need_t)
             part = self._f(cfg.hidden // 64, M, 2)
             ops.gemm_nt_dgelu_stats(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], du, sv['u'], self.Bf[lin], self.Rs[lin], part)
             return self._fold_tail(du, part, sv, lin, f'{pre}.{norm}', dy, dy_t, extra, need_t)

@@ -89,6 +89,9 @@ SIGNATURES = {
     'mbx_augment2d': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp] + [_f] * 8 + [_i, C.c_uint64, _vp]),
     'mbx_embed_fwd_tta': (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     'mbx_flip_average': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mbx_rows_n_pack_bytes': (_sz, [_i]),
+    'mbx_rows_n_pack': (_i, [_vp, _vp, _i, _vp]),
+    'mbx_rows_lnbwd_t': (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
     'mbx_mfma_probe_ws': (_sz, [_i]),
     'mbx_mfma_probe': (_i, [_vp, _i, _i, C.c_uint, _vp, _vp]),
     'mbx_adamw_step': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _i, _vp]),
@@ -324,6 +327,26 @@ class HipOps:
         in the kernel (no LayerNorm pass, no bf16 copy of the residual stream)."""
         M, K = x.shape
         self._ck(self.lib.mbx_rows_gemm_nk_ln(_p(x), _p(packed), _p(bias), _p(rsum), float(eps), _p(out_t), M, out_t.shape[1], K, self._stream()))
+
+    # ------------------------------------------------------------------ N-resident row-owner GEMM + LayerNorm backward (round 5)
+    @staticmethod
+    def can_rows_lnbwd(tdtype, cfg) -> bool:
+        """mbx_rows_lnbwd_t exists for bf16, dim_feat = 512 and contraction lengths (3 C, hidden) that are multiples of 256."""
+        return tdtype == torch.bfloat16 and cfg.C == 512 and cfg.hidden % 256 == 0
+
+    def rows_n_pack(self, w_t):
+        """w bf16 [512, K] (the operand of the dX GEMM) in the fragment order of mbx_rows_lnbwd_t."""
+        N, K = w_t.shape
+        if N != 512:
+            raise RuntimeError(f'rows_n_pack: {N} output columns (512)')
+        packed = torch.empty(int(self.lib.mbx_rows_n_pack_bytes(K)), dtype=torch.uint8, device=w_t.device)
+        self._ck(self.lib.mbx_rows_n_pack(_p(w_t), _p(packed), K, self._stream()))
+        return packed
+
+    def rows_lnbwd_t(self, dy_t, packed, xhat, rstd, dres_t, dx_t):
+        """dx_t = T(dres_t + LayerNorm'(dy . w^T)) with both row means taken in the kernel (no row dots from the producers of dy)."""
+        M, K = dy_t.shape
+        self._ck(self.lib.mbx_rows_lnbwd_t(_p(dy_t), _p(packed), _p(xhat), _p(rstd), _p(dres_t), _p(dx_t), M, dx_t.shape[1], K, self._stream()))
 
     # ------------------------------------------------------------------ measurement aid (bench.py, tools/clock_power.py)
     def mfma_probe(self, seconds: float = 0.25, wgs_per_cu: int = 1, device=None):

@@ -116,6 +116,24 @@ class MockOps:
         if dx_t is not None:
             dx_t.copy_(r.to(dx_t.dtype))
 
+    fuse_rows_lnbwd = True    # tests switch it off to exercise the row-dot sequencing inside a Block too
+
+    def can_rows_lnbwd(self, tdtype, cfg):
+        return bool(self.fuse_rows_lnbwd)
+
+    def rows_n_pack(self, w_t):
+        self._log('rows_n_pack')
+        return w_t
+
+    def rows_lnbwd_t(self, dy_t, packed, xhat, rstd, dres_t, dx_t):
+        """mbx_rows_lnbwd_t: dx_t = T(dres_t + rstd (dxhat - mean dxhat - xhat mean(dxhat xhat))), dxhat = dy . w^T in fp32."""
+        self._log('rows_lnbwd_t')
+        acc = dy_t.float() @ packed.float().t()
+        xh = xhat.float()
+        c1 = acc.mean(-1, keepdim=True)
+        c2 = (acc * xh).mean(-1, keepdim=True)
+        dx_t.copy_((dres_t.float() + rstd[:, None] * (acc - c1 - xh * c2)).to(dx_t.dtype))
+
     def unfold_norm_grads(self, dw, db, w, gamma, beta, dgamma, dbeta):
         """in place: dw <- gamma[k] dw + db[n] beta[k];  dgamma = sum_n w dw';  dbeta = sum_n w db."""
         self._log('unfold_norm_grads')

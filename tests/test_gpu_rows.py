@@ -120,3 +120,39 @@ def test_rows_gemm_rejects_bad_shapes(ops):
     a, w, bias = _operands(64, 96, 256, seed=1)
     with pytest.raises(RuntimeError):
         ops.rows_pack_nk(w)                                  # N % 64
+
+
+@pytest.mark.parametrize('M,K', [(128, 256), (4131, 1536), (4131, 1024), (70227, 1536), (33, 512), (2 * 243 * 17, 1024), (129, 1536), (264384, 1024)])
+def test_rows_lnbwd_t(ops, M, K):
+    """mbx_rows_lnbwd_t (csrc/gemm_rows_n.hip): dX GEMM of a folded (LayerNorm -> Linear) pair + LayerNorm backward with the row means
+    taken from the accumulators, against the torch restatement (fp32 product of the same bf16 operands, exact means) and -- the
+    identity the kernel rests on -- against LayerNorm's backward by autograd on the same dxhat."""
+    N = 512
+    dy = rnd(M, K, seed=M + 1, dtype=BF, scale=0.5)
+    w = rnd(N, K, seed=M + 2, dtype=BF, scale=0.05)
+    x = rnd(M, N, seed=M + 3) * (0.5 + rnd(M, 1, seed=M + 4).abs()) + 0.3 * rnd(M, 1, seed=M + 5)
+    mu = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(((x - mu) ** 2).mean(-1) + 1e-6)
+    xhat = ((x - mu) * rstd[:, None]).to(BF)
+    dres = rnd(M, N, seed=M + 6, dtype=BF)
+    out = torch.full((M, N), float('nan'), device=DEV, dtype=BF)
+    ops.rows_lnbwd_t(dy, ops.rows_n_pack(w), xhat, rstd, dres, out)
+    ref = torch.empty_like(out)
+    MockOps().rows_lnbwd_t(dy, w, xhat, rstd, dres, ref)
+    check(f'rows_lnbwd_t.{M}x{K}', out, ref, 4e-3)
+    # the branch alone (dx - dres) against autograd through the plain normalisation of the same rows, with d(xhat) = dy . w^T in fp32:
+    # the bf16 xhat the kernel reads differs from the exact one by its rounding, hence 1e-2
+    if M <= 8192:
+        xg = x.clone().requires_grad_(True)
+        xh = (xg - xg.mean(-1, keepdim=True)) * torch.rsqrt(xg.var(-1, unbiased=False, keepdim=True) + 1e-6)
+        xh.backward(dy.float() @ w.float().t())
+        check(f'rows_lnbwd_t.vs_autograd.{M}x{K}', out.float() - dres.float(), xg.grad, 2e-2)
+    assert torch.isfinite(out.float()).all()
+
+
+def test_rows_lnbwd_t_rejects_bad_shapes(ops):
+    dy, w = rnd(64, 384, seed=1, dtype=BF), rnd(512, 384, seed=2, dtype=BF)
+    with pytest.raises(RuntimeError):
+        ops.rows_n_pack(w)                                   # K % 256
+    with pytest.raises(RuntimeError):
+        ops.rows_n_pack(rnd(256, 512, seed=3, dtype=BF))     # N != 512

@@ -22,16 +22,20 @@ def _load(model, z):
     assert not missing.missing_keys and not missing.unexpected_keys
 
 
+@pytest.mark.parametrize('rows', [True, False])
 @pytest.mark.parametrize('fold', [True, False])
 @pytest.mark.parametrize('name', ['tiny_default', 'tiny_trained'])
-def test_engine_fp32_matches_reference_gradients(name, fold):
+def test_engine_fp32_matches_reference_gradients(name, fold, rows):
     """Both backward formulations against the reference's autograd gradients: fold=True is the LayerNorm-folded sequencing
-    (LayerNorm backward as the dX GEMM's epilogue from the producers' row dots; the product's bf16 path), fold=False the plain one."""
+    (LayerNorm backward as the dX GEMM's epilogue from the producers' row dots; the product's bf16 path), fold=False the plain one.
+    rows (round 5): inside a Block the folded LayerNorm backward is the epilogue of the row-owner GEMM that takes the row means from its
+    own accumulators (mbx_rows_lnbwd_t) -- the producers then run without their row dots; False: the row-dot sequencing everywhere."""
     z, cfg = load_golden(name)
     model = build_model(cfg)
     _load(model, z)
     model.precision, model.fold_ln = 'fp32', fold
     ops = MockOps()
+    ops.fuse_rows_lnbwd = rows
     x = torch.from_numpy(z['x']).requires_grad_(True)
     out = M.run(ops, model, x)
     assert out.shape == z['out'].shape and out.dtype == torch.float32
@@ -45,14 +49,21 @@ def test_engine_fp32_matches_reference_gradients(name, fold):
     depth = cfg['depth']
     assert ops.calls.count('prep_weights') == 1 and ops.calls.count('fold_norm_weights') == int(fold)
     assert ops.calls.count('gemm_tn') == 8 * 2 * depth + 1
-    sfx = '.stats' if fold else ''
-    assert ops.calls.count('attn_bwd.0' + sfx) == ops.calls.count('attn_bwd.1' + sfx) == 2 * depth
+    rw = fold and rows
+    if rw:      # the first sub-layer of each Block (st: spatial attention, ts: temporal) keeps the row dots, the other attention runs plain
+        assert ops.calls.count('attn_bwd.0.stats') == ops.calls.count('attn_bwd.1.stats') == depth
+        assert ops.calls.count('attn_bwd.0') == ops.calls.count('attn_bwd.1') == depth
+    else:
+        sfx = '.stats' if fold else ''
+        assert ops.calls.count('attn_bwd.0' + sfx) == ops.calls.count('attn_bwd.1' + sfx) == 2 * depth
     # folded: the only stand-alone LayerNorm backward left is the final `norm`; every Block LayerNorm runs as a GEMM epilogue
     assert ops.calls.count('layernorm_bwd') == (1 if fold else 8 * depth + 1)
-    n_lnbwd = ops.calls.count('gemm_nt.lnbwd') + ops.calls.count('gemm_nt.lnbwd.stream')
-    assert n_lnbwd == ops.calls.count('unfold_norm_grads') == ops.calls.count('lnbwd_rowc') == (8 * depth if fold else 0)
+    n_lnbwd = ops.calls.count('gemm_nt.lnbwd') + ops.calls.count('gemm_nt.lnbwd.stream') + ops.calls.count('rows_lnbwd_t')
+    assert n_lnbwd == ops.calls.count('unfold_norm_grads') == (8 * depth if fold else 0)
+    assert ops.calls.count('lnbwd_rowc') == ((2 * depth if rw else 8 * depth) if fold else 0)
     # gradient stream in the operand type: the three inner LayerNorm-backward GEMMs of every Block write no fp32 dx
-    assert ops.calls.count('gemm_nt.lnbwd.stream') == (6 * depth if fold else 0)
+    assert ops.calls.count('gemm_nt.lnbwd.stream') + ops.calls.count('rows_lnbwd_t') == (6 * depth if fold else 0)
+    assert ops.calls.count('rows_lnbwd_t') == ops.calls.count('rows_n_pack') - (2 * depth if rw else 0) == (6 * depth if rw else 0)
     # forward: 8 residual GEMMs per level
     assert ops.calls.count('gemm_nt.2') == 8 * depth
 
@@ -151,7 +162,7 @@ def test_no_grad_raw_operand_sequencing(name):
     # with gradients enabled the training sequencing runs, whatever the provider offers
     ops_g = MockOps()
     M.run(ops_g, model, x.clone().requires_grad_(True)).sum().backward()
-    assert not any(c.startswith('mlp_fused') or c.startswith('rows_') or c.startswith('proj_mlp') for c in ops_g.calls)
+    assert not any(c.startswith('mlp_fused') or c.startswith('rows_gemm') or c.startswith('rows_pack') or c.startswith('proj_mlp') for c in ops_g.calls)
 
 
 def test_average_fusion_variant():
