@@ -38,6 +38,17 @@ __global__ __launch_bounds__(256) void rows_n_pack_kernel(const bf16_t* __restri
     *reinterpret_cast<uint4*>(out + (size_t)frag * 512 + lane * 8) = *reinterpret_cast<const uint4*>(w + (size_t)(32 * nt + i) * K + 16 * kk + 8 * g);
 }
 
+// LDS-DMA with the LDS address as (wave-uniform register + compile-time constant): one scalar register for all ring positions instead of
+// one per position (the peeled last trip doubles their number, and an "s" operand that has been spilled to a VGPR does not assemble)
+__device__ __forceinline__ void rn_glds(const char* base, unsigned voff, unsigned lds_base, int slot_piece) {
+    switch (slot_piece) {      // ring slot * 8 + piece (an asm "n" operand must be a constant at parse time: the switch folds after unrolling)
+#define RG_(p_) case p_: asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_base), "n"(p_ * 4096) : "memory", "scc"); break;
+        RG_(0) RG_(1) RG_(2) RG_(3) RG_(4) RG_(5) RG_(6) RG_(7) RG_(8) RG_(9) RG_(10) RG_(11) RG_(12) RG_(13) RG_(14) RG_(15)
+        RG_(16) RG_(17) RG_(18) RG_(19) RG_(20) RG_(21) RG_(22) RG_(23) RG_(24) RG_(25) RG_(26) RG_(27) RG_(28) RG_(29) RG_(30) RG_(31)
+#undef RG_
+        default: break;
+    }
+}
 template <int N> __device__ __forceinline__ void rn_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __restrict__ dy, const char* __restrict__ wpk,
@@ -81,68 +92,93 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     u32x4_t fb[8];
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
-    // ---- the product: trips of 8 stages = 16 k-steps (the token ring's indices are then static); K % 256 == 0
-    for (int q0 = 0; q0 < nstages; q0 += 8) {
-        const char* const apn = q0 + 8 < nstages ? ap + 512 : ap;      // where the tokens of the next trip's first half are
+    // ---- the product: trips of 8 stages = 16 k-steps (the token ring's indices are then static); K % 256 == 0, K >= 512.
+    // The LAST trip also requests the wave's 32 x 512 slice of xhat, row-major, into registers (four loads per stage in slots 24, 26, 28,
+    // 30: instruction n = 8 j + r4 = rows 4 r4 + xr, 16-byte piece xp of quarter j), so that the epilogue's first input is on chip when
+    // the loop ends -- the per-CU miss bandwidth (~11 B/clk) is what an epilogue costs that starts its loads only then
+    // (v1 of this kernel: 19 us per tile for 384 KiB).  Counted waits of the last trip: every stage issues 8 P + 2 T + 4 X, and the
+    // barrier of its stage u sees 23 (u = 0: the two stages before belong to an ordinary trip), 27 (u = 1) or 31 younger operations.
+    u32x4_t xr_[32];
+    const int xr = lane >> 4, xp = lane & 15;
+    const unsigned dlu = __builtin_amdgcn_readfirstlane(dl);      // (wave-uniform by construction; said again for the "s" operands below)
+    unsigned xoff[8];                              // byte offset of (row 4 r4 + xr, piece xp of quarter 0) in xhat / dres / dx
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int q = q0 + u;
-            unsigned st = fr + (u & 3) * RN_STAGE, sn = fr + ((u + 1) & 3) * RN_STAGE;
-            asm volatile("" : "+v"(st), "+v"(sn));
-            const char* const n3 = wpk + (size_t)min(q + 3, nstages - 1) * RN_STAGE;
-            const char* const n4 = wpk + (size_t)min(q + 4, nstages - 1) * RN_STAGE;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                if (k == 32 - PF) {
-                    if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else rn_vmwait<21>();
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                fb[(k + PF) & 7] = k + PF < 32 ? lds_read16(st, (k + PF) * 1024) : lds_read16(sn, (k + PF - 32) * 1024);
-                // slot k: k-step (k >> 4) of the stage, column tile k & 15
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[k & 15]) : "v"(fb[k & 7]), "v"(tok[(2 * u + (k >> 4)) & 15]));
-                if ((k & 3) == 3) {
-                    if (k < 24) glds16_s(n3 + ((k >> 2) + 2) * 4096, wvo, dl + ((u + 3) & 3) * RN_STAGE + ((k >> 2) + 2) * 4096);
-                    else glds16_s(n4 + ((k >> 2) - 6) * 4096, wvo, dl + ((u + 4) & 3) * RN_STAGE + ((k >> 2) - 6) * 4096);
-                }
-                // tokens of stage q + 4: this trip's second half, or the next trip's first half (in the last trip: this trip's first half
-                // again -- loaded for nothing, but never outside the row)
-                if (k == 25) { if (u < 4) RN_TOK(tok[(2 * (u + 4)) & 15], 32 * (2 * (u + 4))); else RN_TOKN(tok[(2 * (u + 4)) & 15], 32 * (2 * (u - 4))); }
-                if (k == 29) { if (u < 4) RN_TOK(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u + 4) + 1)); else RN_TOKN(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u - 4) + 1)); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        ap += 512;
+    for (int r4 = 0; r4 < 8; ++r4) xoff[r4] = (unsigned)min(mw + 4 * r4 + xr, M - 1) * (RN_N * 2) + xp * 16;
+#define RN_XLD(n_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr_[n_]) : "v"(xoff[(n_) & 7]), "s"(xhat), "n"(((n_) >> 3) * 256) : "memory")
+#define RN_TRIP(LAST_)                                                                                               \
+    {                                                                                                                \
+        const char* const apn = LAST_ ? ap : ap + 512;      /* where the tokens of the next trip's first half are (last trip: this    \
+                                                               trip's first half again -- loaded for nothing, never outside the row) */ \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                              \
+            const int q = q0 + u;                                                                                    \
+            unsigned st = fr + (u & 3) * RN_STAGE, sn = fr + ((u + 1) & 3) * RN_STAGE;                               \
+            asm volatile("" : "+v"(st), "+v"(sn));                                                                   \
+            const char* const n3 = wpk + (size_t)min(q + 3, nstages - 1) * RN_STAGE;                                 \
+            const char* const n4 = wpk + (size_t)min(q + 4, nstages - 1) * RN_STAGE;                                 \
+            _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                         \
+                if (k == 32 - PF) {                                                                                  \
+                    if (LAST_) { if (u == 0) rn_vmwait<23>(); else if (u == 1) rn_vmwait<27>(); else rn_vmwait<31>(); } \
+                    else { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else rn_vmwait<21>(); }    \
+                    __builtin_amdgcn_sched_barrier(0);                                                               \
+                    __builtin_amdgcn_s_barrier();                                                                    \
+                    __builtin_amdgcn_sched_barrier(0);                                                               \
+                }                                                                                                    \
+                fb[(k + PF) & 7] = k + PF < 32 ? lds_read16(st, (k + PF) * 1024) : lds_read16(sn, (k + PF - 32) * 1024); \
+                /* slot k: k-step (k >> 4) of the stage, column tile k & 15 */                                       \
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[k & 15]) : "v"(fb[k & 7]), "v"(tok[(2 * u + (k >> 4)) & 15])); \
+                if ((k & 3) == 3) {                                                                                  \
+                    if (k < 24) rn_glds(n3 + ((k >> 2) + 2) * 4096, wvo, dlu, ((u + 3) & 3) * 8 + (k >> 2) + 2);                     \
+                    else rn_glds(n4 + ((k >> 2) - 6) * 4096, wvo, dlu, ((u + 4) & 3) * 8 + (k >> 2) - 6);                             \
+                }                                                                                                    \
+                if (k == 25) { if (u < 4) RN_TOK(tok[(2 * (u + 4)) & 15], 32 * (2 * (u + 4))); else RN_TOKN(tok[(2 * (u + 4)) & 15], 32 * (2 * (u - 4))); } \
+                if (k == 29) { if (u < 4) RN_TOK(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u + 4) + 1)); else RN_TOKN(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u - 4) + 1)); } \
+                if (LAST_ && k >= 24 && !(k & 1)) RN_XLD(4 * u + ((k - 24) >> 1));                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                                   \
+            }                                                                                                        \
+        }                                                                                                            \
+        ap += 512;                                                                                                   \
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the re-read tail stages and the over-read tokens have landed
-    __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring: it becomes four 8-KiB buffers per wave
+    int q0 = 0;
+    for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false)
+    RN_TRIP(true)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the re-read tail stages, the over-read tokens and xhat have landed
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring: 32 KiB of it per wave are buffers now
 #pragma unroll
     for (int t = 0; t < 16; ++t) MFMA_PAD_A(acc[t]);
+#pragma unroll
+    for (int n = 0; n < 32; n += 8)                                  // (data dependence on the wait above for the registers the asm loads wrote)
+        asm volatile("" : "+v"(xr_[n]), "+v"(xr_[n + 1]), "+v"(xr_[n + 2]), "+v"(xr_[n + 3]), "+v"(xr_[n + 4]), "+v"(xr_[n + 5]), "+v"(xr_[n + 6]), "+v"(xr_[n + 7]));
 
-    // ---- epilogue.  Quarter j of a row (columns [128 j, 128 j + 128), 256 bytes of bf16) of xhat / dres arrives in one of the wave's four
-    // 8-KiB buffers by LDS-DMA: one instruction = 4 rows x 256 bytes; 16-byte piece p of row r at slot p ^ (r & 15) (applied to the
-    // source address).  A lane reads its accumulator positions (row i, columns 32 ntl + 8 qq + 4 g + e) as 8-byte halves of pieces.
-    // Pass 1: the four quarters of xhat -> the two row means.  Pass 2, per quarter (double-buffered in buffer pairs): xhat again
-    // (L2-hot: keeping it in registers instead costs 128 of them and spills) + dres -> dx, written over the dres it was made from,
-    // read back row-major and stored as whole 256-byte row segments.
+    // ---- epilogue.  The wave's 32 KiB of the ring take its 32 x 512 slice of xhat (four quarters of 128 columns, written from the
+    // registers the last trip filled); a fifth 8-KiB buffer per wave behind the ring (the kernel uses all 160 KiB of LDS) takes one
+    // quarter of dres at a time, which arrives through registers too (eight row-major loads per quarter, two quarters ahead).  In a
+    // buffer row r takes 256 bytes and its 16-byte piece p sits at slot p ^ (r & 15); a lane reads its accumulator positions (row i,
+    // columns 32 ntl + 8 qq + 4 g + e of the quarter) as 8-byte halves of pieces.
+    //   pass 1: the two row means from the accumulators and xhat;
+    //   pass 2, per quarter: dres -> buffer, dx written over the dres it was made from, read back row-major, stored as whole 256-byte
+    //   row segments.
+    // (lane-derived values are re-derived from an opaque copy of the thread index: otherwise they are carried through the loop in registers
+    // the last trip needs)
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
-    const int lane_e = tid_e & 63, i_e = lane_e & 31, g_e = lane_e >> 5;
+    const int lane_e = tid_e & 63, i_e = lane_e & 31, g_e = lane_e >> 5, xr_e = lane_e >> 4, xp_e = lane_e & 15;
     char* const eb = ring + wave * 32768;
-    const int xr = lane_e >> 4, xp = lane_e & 15;
-    auto issue_q = [&](const bf16_t* src, int j, char* buf) {      // 8 instructions
+    char* const bd = ring + RN_RING + wave * 8192;
 #pragma unroll
-        for (int r4 = 0; r4 < 8; ++r4) {
-            const int rl = 4 * r4 + xr;
-            GLDS16(src + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp ^ (rl & 15)) << 3), buf + r4 * 1024);
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue_q(xhat, j, eb + j * 8192);
+    for (int n = 0; n < 32; ++n) {                 // quarter n >> 3, rows 4 (n & 7) + xr
+        const int rl = 4 * (n & 7) + xr_e;
+        *reinterpret_cast<u32x4_t*>(eb + (n >> 3) * 8192 + rl * 256 + ((xp_e ^ (rl & 15)) << 4)) = xr_[n];
+    }
+    u32x4_t dq[2][8];
+#define RN_DLD(b_, j_) _Pragma("unroll") for (int r4_ = 0; r4_ < 8; ++r4_)                                           \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dq[b_][r4_]) : "v"(xoff[r4_]), "s"(dres_t), "n"((j_) * 256) : "memory")
+#define RN_DWAIT(b_, n_) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(dq[b_][0]), "+v"(dq[b_][1]), "+v"(dq[b_][2]), "+v"(dq[b_][3]), "+v"(dq[b_][4]), \
+                                      "+v"(dq[b_][5]), "+v"(dq[b_][6]), "+v"(dq[b_][7]) : "n"(n_) : "memory")
+    RN_DLD(0, 0);
+    RN_DLD(1, 1);
     const float rs = rstd[min(mw + i_e, M - 1)];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float c1 = 0.f, c2 = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the rows a lane reads were written by other lanes of THIS wave: in order)
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) {
         const f32x16_t t = acc[nt];
@@ -159,23 +195,24 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     c1 = wave_halves<WaveAdd>(c1) * (1.0f / (float)RN_N);             // the two halves of row i: lanes i and i + 32
     c2 = wave_halves<WaveAdd>(c2) * (1.0f / (float)RN_N);
     const float k1 = -rs * c1, k2 = -rs * c2;                         // dx = dres + rs t + k1 + k2 xhat
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the buffers have been read out
-    // quarter j lives in the buffer pair 2 (j & 1): xhat in the first, dres (then dx) in the second
-    issue_q(xhat, 0, eb); issue_q(dres_t, 0, eb + 8192);
-    issue_q(xhat, 1, eb + 16384); issue_q(dres_t, 1, eb + 24576);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        // vector memory operations younger than quarter j's requests: quarter j + 1's (16) and the stores of quarter j - 1 (8) in between
-        if (j == 0) rn_vmwait<16>(); else if (j < 3) rn_vmwait<24>(); else rn_vmwait<8>();
-        char* const bx = eb + (j & 1) * 16384;
-        char* const bd = bx + 8192;
+        // vector memory operations younger than the loads of quarter j: [the stores of quarter j - 1 (8)] + the loads of quarter j + 1 (8)
+        if (j == 0) { RN_DWAIT(0, 8); } else if (j == 1) { RN_DWAIT(1, 16); } else if (j == 2) { RN_DWAIT(0, 16); } else { RN_DWAIT(1, 8); }
+#pragma unroll
+        for (int r4 = 0; r4 < 8; ++r4) {
+            const int rl = 4 * r4 + xr_e;
+            *reinterpret_cast<u32x4_t*>(bd + rl * 256 + ((xp_e ^ (rl & 15)) << 4)) = dq[j & 1][r4];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j + 2 < 4) { if (j == 0) { RN_DLD(0, 2); } else { RN_DLD(1, 3); } }      // the registers are free again: the quarter after next
 #pragma unroll
         for (int ntl = 0; ntl < 4; ++ntl) {
             const f32x16_t t = acc[4 * j + ntl];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int off = i_e * 256 + (((ntl * 4 + qq) ^ (i_e & 15)) << 4) + 8 * g_e;
-                const uint2 xv = *reinterpret_cast<const uint2*>(bx + off);
+                const uint2 xv = *reinterpret_cast<const uint2*>(eb + j * 8192 + off);
                 uint2* const p = reinterpret_cast<uint2*>(bd + off);
                 const uint2 dv = *p;
                 const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
@@ -188,22 +225,16 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the quarter leaves row-major: one instruction = 4 rows x 256 bytes (the lanes that wrote a row are other lanes of THIS wave,
-        // and LDS executes a wave's instructions in order; the asm statement keeps the compiler from moving the reads above the writes)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int r4 = 0; r4 < 8; ++r4) {
-            const int rl = 4 * r4 + xr;
+            const int rl = 4 * r4 + xr_e;
             const uint4 v = *reinterpret_cast<const uint4*>(bd + r4 * 1024 + lane_e * 16);
             // rows past M were computed from row M - 1's inputs (every load is clamped) and are stored onto row M - 1: identical bytes,
             // and every wave issues the same number of vector memory instructions -- the counted waits above depend on it
-            *reinterpret_cast<uint4*>(dx_t + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp ^ (rl & 15)) << 3)) = v;
+            *reinterpret_cast<uint4*>(dx_t + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp_e ^ (rl & 15)) << 3)) = v;
         }
-        if (j + 2 < 4) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the pair has been read out
-            issue_q(xhat, j + 2, bx);
-            issue_q(dres_t, j + 2, bd);
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the buffer has been read out before the next quarter overwrites it
     }
 }
 
@@ -212,7 +243,7 @@ extern "C" size_t mbx_rows_n_pack_bytes(int K) { return (size_t)RN_N * K * sizeo
 
 extern "C" int mbx_rows_n_pack(const void* w, void* packed, int K, void* stream) {
     MBX_CHECK_ARG(w && packed, "rows_n_pack: null pointer");
-    MBX_CHECK_ARG(K > 0 && K % 256 == 0, "rows_n_pack: K=%d (%% 256)", K);
+    MBX_CHECK_ARG(K >= 512 && K % 256 == 0, "rows_n_pack: K=%d (%% 256, >= 512)", K);
     const int nfrag = (K / 16) * 16;
     hipLaunchKernelGGL(rows_n_pack_kernel, dim3((nfrag + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)packed, K);
     MBX_LAUNCH_CHECK("rows_n_pack");
@@ -222,9 +253,10 @@ extern "C" int mbx_rows_n_pack(const void* w, void* packed, int K, void* stream)
 extern "C" int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* xhat, const float* rstd, const void* dres_t, void* dx_t,
                                 int M, int N, int K, void* stream) {
     MBX_CHECK_ARG(dy && packed && xhat && rstd && dres_t && dx_t, "rows_lnbwd_t: null pointer");
-    MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 256 && K % 256 == 0, "rows_lnbwd_t: bad shape M=%d N=%d (512) K=%d (%% 256)", M, N, K);
-    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_lnbwd_kernel), RN_RING, "rows_lnbwd_t")) return 1;
-    hipLaunchKernelGGL(rows_n_lnbwd_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING, (hipStream_t)stream, (const bf16_t*)dy,
+    MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 512 && K % 256 == 0, "rows_lnbwd_t: bad shape M=%d N=%d (512) K=%d (%% 256, >= 512)", M, N, K);
+    MBX_CHECK_ARG((size_t)M * RN_N * 2 < ((size_t)1 << 32), "rows_lnbwd_t: M=%d rows of 1 KiB exceed the 32-bit row offsets of the kernel", M);
+    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_lnbwd_kernel), RN_RING + 4 * 8192, "rows_lnbwd_t")) return 1;
+    hipLaunchKernelGGL(rows_n_lnbwd_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)dy,
                        (const char*)packed, (const bf16_t*)xhat, rstd, (const bf16_t*)dres_t, (bf16_t*)dx_t, M, K);
     MBX_LAUNCH_CHECK("rows_lnbwd_t");
     return 0;

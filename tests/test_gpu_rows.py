@@ -122,7 +122,7 @@ def test_rows_gemm_rejects_bad_shapes(ops):
         ops.rows_pack_nk(w)                                  # N % 64
 
 
-@pytest.mark.parametrize('M,K', [(128, 256), (4131, 1536), (4131, 1024), (70227, 1536), (33, 512), (2 * 243 * 17, 1024), (129, 1536), (264384, 1024)])
+@pytest.mark.parametrize('M,K', [(128, 512), (4131, 1536), (4131, 1024), (70227, 1536), (33, 512), (2 * 243 * 17, 1024), (129, 1536), (264384, 1024), (300, 768)])
 def test_rows_lnbwd_t(ops, M, K):
     """mbx_rows_lnbwd_t (csrc/gemm_rows_n.hip): dX GEMM of a folded (LayerNorm -> Linear) pair + LayerNorm backward with the row means
     taken from the accumulators, against the torch restatement (fp32 product of the same bf16 operands, exact means) and -- the
