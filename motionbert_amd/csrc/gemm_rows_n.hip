@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     // The LAST trip also requests the wave's 32 x 512 slice of xhat, row-major, into registers (four loads per stage in slots 24, 26, 28,
     // 30: instruction n = 8 j + r4 = rows 4 r4 + xr, 16-byte piece xp of quarter j), so that the epilogue's first input is on chip when
     // the loop ends -- the per-CU miss bandwidth (~11 B/clk) is what an epilogue costs that starts its loads only then
-    // (v1 of this kernel: 19 us per tile for 384 KiB).  Counted waits of the last trip: every stage issues 8 P + 2 T + 4 X, and the
-    // barrier of its stage u sees 23 (u = 0: the two stages before belong to an ordinary trip), 27 (u = 1) or 31 younger operations.
+    // (v1 of this kernel: 19 us per tile for 384 KiB).  Counted waits of the last trip: a stage issues 8 P + 4 X and, in its first half,
+    // 2 T (there is no next trip to fetch tokens for); the barrier of its stage u sees 23 (u = 0: the two stages before belong to an
+    // ordinary trip), 27, 31, 31, 30, 28, 26, 26 younger operations.
     u32x4_t xr_[32];
     const int xr = lane >> 4, xp = lane & 15;
     const unsigned dlu = __builtin_amdgcn_readfirstlane(dl);      // (wave-uniform by construction; said again for the "s" operands below)
@@ -107,8 +108,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
 #define RN_XLD(n_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr_[n_]) : "v"(xoff[(n_) & 7]), "s"(xhat), "n"(((n_) >> 3) * 256) : "memory")
 #define RN_TRIP(LAST_)                                                                                               \
     {                                                                                                                \
-        const char* const apn = LAST_ ? ap : ap + 512;      /* where the tokens of the next trip's first half are (last trip: this    \
-                                                               trip's first half again -- loaded for nothing, never outside the row) */ \
+        const char* const apn = ap + 512;                   /* where the tokens of the next trip's first half are */                   \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                              \
             const int q = q0 + u;                                                                                    \
             unsigned st = fr + (u & 3) * RN_STAGE, sn = fr + ((u + 1) & 3) * RN_STAGE;                               \
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             const char* const n4 = wpk + (size_t)min(q + 4, nstages - 1) * RN_STAGE;                                 \
             _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                         \
                 if (k == 32 - PF) {                                                                                  \
-                    if (LAST_) { if (u == 0) rn_vmwait<23>(); else if (u == 1) rn_vmwait<27>(); else rn_vmwait<31>(); } \
+                    if (LAST_) { if (u == 0) rn_vmwait<23>(); else if (u == 1) rn_vmwait<27>(); else if (u < 4) rn_vmwait<31>();      \
+                                 else if (u == 4) rn_vmwait<30>(); else if (u == 5) rn_vmwait<28>(); else rn_vmwait<26>(); }      \
                     else { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else rn_vmwait<21>(); }    \
                     __builtin_amdgcn_sched_barrier(0);                                                               \
                     __builtin_amdgcn_s_barrier();                                                                    \
@@ -130,8 +131,10 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
                     if (k < 24) rn_glds(n3 + ((k >> 2) + 2) * 4096, wvo, dlu, ((u + 3) & 3) * 8 + (k >> 2) + 2);                     \
                     else rn_glds(n4 + ((k >> 2) - 6) * 4096, wvo, dlu, ((u + 4) & 3) * 8 + (k >> 2) - 6);                             \
                 }                                                                                                    \
-                if (k == 25) { if (u < 4) RN_TOK(tok[(2 * (u + 4)) & 15], 32 * (2 * (u + 4))); else RN_TOKN(tok[(2 * (u + 4)) & 15], 32 * (2 * (u - 4))); } \
-                if (k == 29) { if (u < 4) RN_TOK(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u + 4) + 1)); else RN_TOKN(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u - 4) + 1)); } \
+                /* (no token loads in the second half of the LAST trip: a register an asm load writes but nobody reads is dead to the   \
+                   compiler, which hands it to something else -- and the load lands in it later) */                                     \
+                if (k == 25) { if (u < 4) RN_TOK(tok[(2 * (u + 4)) & 15], 32 * (2 * (u + 4))); else if (!LAST_) RN_TOKN(tok[(2 * (u + 4)) & 15], 32 * (2 * (u - 4))); } \
+                if (k == 29) { if (u < 4) RN_TOK(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u + 4) + 1)); else if (!LAST_) RN_TOKN(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u - 4) + 1)); } \
                 if (LAST_ && k >= 24 && !(k & 1)) RN_XLD(4 * u + ((k - 24) >> 1));                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                                   \
             }                                                                                                        \
@@ -151,12 +154,14 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
 
     // ---- epilogue.  The wave's 32 KiB of the ring take its 32 x 512 slice of xhat (four quarters of 128 columns, written from the
     // registers the last trip filled); a fifth 8-KiB buffer per wave behind the ring (the kernel uses all 160 KiB of LDS) takes one
-    // quarter of dres at a time, which arrives through registers too (eight row-major loads per quarter, two quarters ahead).  In a
-    // buffer row r takes 256 bytes and its 16-byte piece p sits at slot p ^ (r & 15); a lane reads its accumulator positions (row i,
-    // columns 32 ntl + 8 qq + 4 g + e of the quarter) as 8-byte halves of pieces.
+    // quarter of dres at a time, by LDS-DMA: no registers, and nothing the compiler could move (an earlier version fetched dres with
+    // asm loads into registers: under this epilogue's register pressure the compiler gave all eight loads of a quarter ONE destination
+    // and copied it out before the data had landed -- an asm output is "defined" where the statement stands).  In a buffer row r takes
+    // 256 bytes and its 16-byte piece p sits at slot p ^ (r & 15); a lane reads its accumulator positions (row i, columns
+    // 32 ntl + 8 qq + 4 g + e of the quarter) as 8-byte halves of pieces.
     //   pass 1: the two row means from the accumulators and xhat;
-    //   pass 2, per quarter: dres -> buffer, dx written over the dres it was made from, read back row-major, stored as whole 256-byte
-    //   row segments.
+    //   pass 2, per quarter: dx written over the xhat it was made from, read back row-major, stored as whole 256-byte row segments;
+    //   the next quarter of dres is requested as soon as this one has been read, and lands while this one's dx is read out and stored.
     // (lane-derived values are re-derived from an opaque copy of the thread index: otherwise they are carried through the loop in registers
     // the last trip needs)
     int tid_e = threadIdx.x;
@@ -164,18 +169,23 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     const int lane_e = tid_e & 63, i_e = lane_e & 31, g_e = lane_e >> 5, xr_e = lane_e >> 4, xp_e = lane_e & 15;
     char* const eb = ring + wave * 32768;
     char* const bd = ring + RN_RING + wave * 8192;
+    const unsigned bdl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const lds_void_t*)ring + RN_RING + wave * 8192);
+    // DMA instruction r4 fills rows 4 r4 .. 4 r4 + 3 of the buffer: lane (xr, xp) lands in slot xp of row rl = 4 r4 + xr, so it fetches
+    // piece xp ^ (rl & 15) of that row
+    unsigned doff[8];
+#pragma unroll
+    for (int r4 = 0; r4 < 8; ++r4) {
+        const int rl = 4 * r4 + xr_e;
+        doff[r4] = (unsigned)min(mw + rl, M - 1) * (RN_N * 2) + ((xp_e ^ (rl & 15)) << 4);
+    }
+#define RN_DDMA(j_) _Pragma("unroll") for (int r4_ = 0; r4_ < 8; ++r4_)                                              \
+        glds16_s(reinterpret_cast<const char*>(dres_t) + (j_) * 256, doff[r4_], bdl + r4_ * 1024)
+    RN_DDMA(0);
 #pragma unroll
     for (int n = 0; n < 32; ++n) {                 // quarter n >> 3, rows 4 (n & 7) + xr
         const int rl = 4 * (n & 7) + xr_e;
         *reinterpret_cast<u32x4_t*>(eb + (n >> 3) * 8192 + rl * 256 + ((xp_e ^ (rl & 15)) << 4)) = xr_[n];
     }
-    u32x4_t dq[2][8];
-#define RN_DLD(b_, j_) _Pragma("unroll") for (int r4_ = 0; r4_ < 8; ++r4_)                                           \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dq[b_][r4_]) : "v"(xoff[r4_]), "s"(dres_t), "n"((j_) * 256) : "memory")
-#define RN_DWAIT(b_, n_) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(dq[b_][0]), "+v"(dq[b_][1]), "+v"(dq[b_][2]), "+v"(dq[b_][3]), "+v"(dq[b_][4]), \
-                                      "+v"(dq[b_][5]), "+v"(dq[b_][6]), "+v"(dq[b_][7]) : "n"(n_) : "memory")
-    RN_DLD(0, 0);
-    RN_DLD(1, 1);
     const float rs = rstd[min(mw + i_e, M - 1)];
     float c1 = 0.f, c2 = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the rows a lane reads were written by other lanes of THIS wave: in order)
@@ -197,44 +207,37 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     const float k1 = -rs * c1, k2 = -rs * c2;                         // dx = dres + rs t + k1 + k2 xhat
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        // vector memory operations younger than the loads of quarter j: [the stores of quarter j - 1 (8)] + the loads of quarter j + 1 (8)
-        if (j == 0) { RN_DWAIT(0, 8); } else if (j == 1) { RN_DWAIT(1, 16); } else if (j == 2) { RN_DWAIT(0, 16); } else { RN_DWAIT(1, 8); }
-#pragma unroll
-        for (int r4 = 0; r4 < 8; ++r4) {
-            const int rl = 4 * r4 + xr_e;
-            *reinterpret_cast<u32x4_t*>(bd + rl * 256 + ((xp_e ^ (rl & 15)) << 4)) = dq[j & 1][r4];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (j + 2 < 4) { if (j == 0) { RN_DLD(0, 2); } else { RN_DLD(1, 3); } }      // the registers are free again: the quarter after next
+        // vector memory operations younger than the DMA of quarter j: the stores of quarter j - 1 (8)
+        if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #pragma unroll
         for (int ntl = 0; ntl < 4; ++ntl) {
             const f32x16_t t = acc[4 * j + ntl];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int off = i_e * 256 + (((ntl * 4 + qq) ^ (i_e & 15)) << 4) + 8 * g_e;
-                const uint2 xv = *reinterpret_cast<const uint2*>(eb + j * 8192 + off);
-                uint2* const p = reinterpret_cast<uint2*>(bd + off);
-                const uint2 dv = *p;
+                uint2* const p = reinterpret_cast<uint2*>(eb + j * 8192 + off);
+                const uint2 xv = *p;
+                const uint2 dv = *reinterpret_cast<const uint2*>(bd + off);
                 const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
                 const float d2 = __uint_as_float(dv.y << 16), d3 = __uint_as_float(dv.y & 0xffff0000u);
                 const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
                 const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
                 const float o0 = fmaf(rs, t[4 * qq], fmaf(k2, x0, d0 + k1)), o1 = fmaf(rs, t[4 * qq + 1], fmaf(k2, x1, d1 + k1));
                 const float o2 = fmaf(rs, t[4 * qq + 2], fmaf(k2, x2, d2 + k1)), o3 = fmaf(rs, t[4 * qq + 3], fmaf(k2, x3, d3 + k1));
-                *p = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));  // over the dres value it was made from: same lane, same place
+                *p = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));  // over the xhat value it was made from: same lane, same place
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // dres has been read (the buffer is free), dx is in place
+        if (j == 0) { RN_DDMA(1); } else if (j == 1) { RN_DDMA(2); } else if (j == 2) { RN_DDMA(3); }
 #pragma unroll
         for (int r4 = 0; r4 < 8; ++r4) {
             const int rl = 4 * r4 + xr_e;
-            const uint4 v = *reinterpret_cast<const uint4*>(bd + r4 * 1024 + lane_e * 16);
+            const uint4 v = *reinterpret_cast<const uint4*>(eb + j * 8192 + r4 * 1024 + lane_e * 16);
             // rows past M were computed from row M - 1's inputs (every load is clamped) and are stored onto row M - 1: identical bytes,
             // and every wave issues the same number of vector memory instructions -- the counted waits above depend on it
             *reinterpret_cast<uint4*>(dx_t + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp_e ^ (rl & 15)) << 3)) = v;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the buffer has been read out before the next quarter overwrites it
     }
 }
 
