@@ -106,6 +106,8 @@ class TimedOps:
                 flops = 2.0 * first(a[0]).shape[0] * first(a[1]).shape[0] * first(a[0]).shape[1]
             elif name == 'gemm_tn':
                 flops = 2.0 * first(a[0]).shape[0] * first(a[0]).shape[1] * first(a[1]).shape[1]
+            elif name == 'rows_lnbwd_t':        # (dy [M, K], packed W'^T, xhat [M, 512], ...): the row-owner dX GEMM of a folded pair
+                flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[2].shape[1]
             self.rec.append((name, flops, e0, e1))
             return r
         return wrapped
@@ -782,7 +784,7 @@ def main():
         intensity = fpl / traffic if traffic else None
         bound = 'hbm' if intensity is not None and intensity < peak / HBM_ACHIEVABLE_TBS else 'mfma'
         hbm_tbs = traffic / avg_s / 1e12 if traffic else None
-        roof = dict(bound=bound, kernel='mbx_gemm_nt / mbx_gemm_nt_dgelu_stats / mbx_gemm_nt_lnbwd -> gemm_nt_pp256_kernel (store, GELU, dGELU epilogues) / gemm_nt_pipe_kernel (residual and LayerNorm-backward epilogues) (bf16 MFMA GEMM, all 162 launches of a step)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+        roof = dict(bound=bound, kernel='mbx_gemm_nt / mbx_gemm_nt_dgelu_stats / mbx_gemm_nt_lnbwd -> gemm_nt_pp256_kernel (store, GELU, dGELU epilogues) / gemm_nt_pipe_kernel (residual and LayerNorm-backward epilogues) (bf16 MFMA GEMM, every launch of a step: `launches`)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                     traffic=traffic, traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt kernels)',
                     traffic_source=('STATIC: ' + os.path.relpath(PMC_TABLE, ROOT) + ' (separate rocprofv3 --pmc passes of this command on this round\'s kernels: '
                                     'FETCH_SIZE x2 + WRITE_SIZE); not measured by this run') if os.path.exists(PMC_TABLE) else None, launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
@@ -806,7 +808,7 @@ def main():
             roof['sustained_error'] = f'{type(e).__name__}: {e}'[:200]
         roof['by_entry'] = {k: dict(launches=agg[k]['calls'], ms=round(agg[k]['ms'], 3), tflops=round(agg[k]['flops'] / (agg[k]['ms'] * 1e-3) / 1e12, 1),
                                     frac=round(agg[k]['flops'] / (agg[k]['ms'] * 1e-3) / 1e12 / peak, 4))
-                            for k in NT_FAMILY + ('gemm_tn',) if k in agg and agg[k]['ms'] > 0}
+                            for k in NT_FAMILY + ('gemm_tn', 'rows_lnbwd_t') if k in agg and agg[k]['ms'] > 0}
     flops_step = wl_flops if wl_flops is not None else 3.0 * model_flops_fwd(FULL, T) * B
     out = {
         'metric': 'clips/sec [B,243,17,3] DSTformer fwd+bwd', 'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world,
