@@ -109,6 +109,95 @@ __global__ __launch_bounds__(256, 1) void stream_kernel(const char* __restrict__
     sink[blockIdx.x * blockDim.x + tid] = s;
 }
 
+// ---- the same product with every weight fragment used TWICE (round 5, third question): a wave owns 64 rows x 256 columns (two row
+// blocks x eight column tiles = the same 256 accumulators); waves 2 rg + ch: row group rg, column half ch.  A stage is still 32 MFMA
+// slots per wave, but only 16 fragment reads (LDS reads per flop halved: 64 B/clk per CU at the full matrix rate instead of 128 = the
+// port), and four token loads (two row blocks x two k-steps) three stages ahead, issued in slots 0, 1, 4, 5 so that they are OLDER than
+// the weight piece the barrier waits for.  Slot order of a stage: T0 T1 P3 T4 T5 P7 P11 P15 P19 P23 | barrier (slot 24) | P27 P31;
+// "stage q + 1 has landed" leaves (q-2: P P) + (q-1: 12) + (q: 10) = 24 younger operations in flight (first stage of a launch: 20).
+template <int FILL>
+__global__ __launch_bounds__(256, 1) void stream2_kernel(const char* __restrict__ wpk, const uint16_t* __restrict__ a, float* __restrict__ sink, int K, int Mrows) {
+    constexpr int PFF = 4;                           // fragments read ahead (each feeds two MFMAs)
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5, rg = wave >> 1, ch = wave & 1;
+    const unsigned fr = (unsigned)(uintptr_t)(const lds_void_t*)ring + lane * 16 + ch * 8192;      // this wave's column half of a k-step
+    const unsigned wvo = wave * 1024 + lane * 16;
+    const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
+    f32x16_t acc[16];                                // [rb * 8 + f]
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float fv[4] = {1.0f + lane * 1e-3f, 0.5f, 0.25f, 0.125f};
+    const int nstages = K / 32;
+    const int row0 = min((int)blockIdx.x * 128 + rg * 64 + i, Mrows - 1), row1 = min((int)blockIdx.x * 128 + rg * 64 + 32 + i, Mrows - 1);
+    const char* ap0 = reinterpret_cast<const char*>(a + (size_t)row0 * K + 8 * g);      // + 32 bytes per k-step
+    const char* ap1 = reinterpret_cast<const char*>(a + (size_t)row1 * K + 8 * g);
+    u32x4_t tok[16];                                 // [(stage & 3) * 4 + ks * 2 + rb]
+    auto issue = [&](int q, int j) { glds16_s(wpk + (size_t)(q % NSTREAM) * STAGE + (size_t)j * 4 * 1024, wvo, dl + (q & 3) * STAGE + j * 4 * 1024); };
+#define TOK2(dst_, rb_, off_) do { if (rb_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst_) : "v"(ap1), "n"(off_) : "memory"); \
+                                   else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst_) : "v"(ap0), "n"(off_) : "memory"); } while (0)
+    // preamble: tokens of stages 0..2, then the ring
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) TOK2(tok[q * 4 + e], e & 1, q * 64 + (e >> 1) * 32);
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue(q, j);
+    issue(3, 0);
+    issue(3, 1);
+    vmwait<18>();
+    __syncthreads();
+    u32x4_t fb[8];
+#pragma unroll
+    for (int j = 0; j < PFF; ++j) fb[j] = lds_read16(fr, ((j >> 3) * 16 + (j & 7)) * 1024);
+    for (int q0 = 0; q0 < nstages; q0 += 4) {          // 4 stages per trip: the token ring's indices are static
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u;
+            unsigned st = fr + u * STAGE, sn = fr + ((u + 1) & 3) * STAGE;
+            asm volatile("" : "+v"(st), "+v"(sn));
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                if (k == 32 - 2 * PFF) {
+                    if (u == 0) vmwait<20>(); else vmwait<24>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!(k & 1)) {
+                    const int j = (k >> 1) + PFF;
+                    fb[j & 7] = j < 16 ? lds_read16(st, ((j >> 3) * 16 + (j & 7)) * 1024) : lds_read16(sn, (((j - 16) >> 3) * 16 + ((j - 16) & 7)) * 1024);
+                }
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[(k & 1) * 8 + ((k & 15) >> 1)]) : "v"(fb[(k >> 1) & 7]), "v"(tok[u * 4 + (k >> 4) * 2 + (k & 1)]));
+                if ((k & 3) == 3) { if (k < 24) issue(q + 3, (k >> 2) + 2); else issue(q + 4, (k >> 2) - 6); }
+                // tokens of stage q + 3 into the ring slot of stage q - 1 (consumed): slots 0, 1 (k-step 0), 4, 5 (k-step 1)
+                if (k == 0) TOK2(tok[((u + 3) & 3) * 4 + 0], 0, (u + 3) * 64);
+                if (k == 1) TOK2(tok[((u + 3) & 3) * 4 + 1], 1, (u + 3) * 64);
+                if (k == 4) TOK2(tok[((u + 3) & 3) * 4 + 2], 0, (u + 3) * 64 + 32);
+                if (k == 5) TOK2(tok[((u + 3) & 3) * 4 + 3], 1, (u + 3) * 64 + 32);
+#pragma unroll
+                for (int f = 0; f < FILL; ++f) fv[f & 3] = fmaf(fv[f & 3], fv[(f + 1) & 3], 0.001f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        ap0 += 256;
+        ap1 += 256;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = fv[0] + fv[1] + fv[2] + fv[3];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        asm volatile("s_nop 7" : "+a"(acc[t]));
+        s += acc[t][0] + acc[t][15];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) asm volatile("" :: "v"(tok[t]));      // (no asm load without a reader)
+    sink[blockIdx.x * blockDim.x + tid] = s;
+}
+
 template <int SHAPE, int FILL, bool DMA>
 __global__ __launch_bounds__(SHAPE ? 512 : 256, 1) void loop_kernel(const char* __restrict__ wpk, float* __restrict__ sink, int tiles) {
     constexpr int NW = SHAPE ? 8 : 4;            // waves per workgroup
@@ -226,6 +315,26 @@ static void run_stream(const char* name, const char* wpk, const uint16_t* a, flo
            ms * 1e3 / rounds, ms * 1e3 / rounds / stages, hipGetErrorString(hipGetLastError()));
 }
 
+template <int FILL>
+static void run_stream2(const char* name, const char* wpk, const uint16_t* a, float* sink, int K, int M) {
+    auto k = stream2_kernel<FILL>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, RING);
+    const int blocks = (M + 127) / 128;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), RING, 0, wpk, a, sink, K, M);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), RING, 0, wpk, a, sink, K, M);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double rounds = (double)blocks / 256.0, stages = K / 32.0;
+    printf("%-44s M=%d K=%d: %7.3f ms = %5.0f TFLOP/s; %6.2f us per tile round, %5.3f us per stage   (%s)\n", name, M, K, ms, 2.0 * M * 512.0 * K / ms / 1e9,
+           ms * 1e3 / rounds, ms * 1e3 / rounds / stages, hipGetErrorString(hipGetLastError()));
+}
+
 int main() {
     const size_t nb = (size_t)NSTREAM * STAGE;
     std::vector<uint16_t> h(nb / 2);
@@ -261,6 +370,14 @@ int main() {
         run_stream<0>("streamed tokens, whole rounds only", wpk, a, sink2, 1536, Mfull);
         run_stream<0>("streamed tokens, whole rounds only", wpk, a, sink2, 1024, Mfull);
         run_stream<0>("streamed tokens", wpk, a, sink2, 512, M);
+        printf("# the same with 64 rows x 256 columns per wave (every weight fragment feeds two MFMAs)\n");
+        run_stream2<0>("64 x 256 per wave", wpk, a, sink2, 1536, M);
+        run_stream2<0>("64 x 256 per wave", wpk, a, sink2, 1024, M);
+        run_stream2<0>("64 x 256 per wave, whole rounds only", wpk, a, sink2, 1536, Mfull);
+        run_stream2<0>("64 x 256 per wave, whole rounds only", wpk, a, sink2, 1024, Mfull);
+        run_stream2<0>("64 x 256 per wave", wpk, a, sink2, 512, M);
+        run_stream2<3>("64 x 256 per wave + 3 VALU per slot", wpk, a, sink2, 1536, Mfull);
+        run_stream<3>("32 x 512 per wave + 3 VALU per slot", wpk, a, sink2, 1536, Mfull);
     }
     return 0;
 }
