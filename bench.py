@@ -79,7 +79,7 @@ def pose_loss(pred, gt):
 
 # the NT GEMM entries of the C ABI (same kernels, different epilogues): mbx_gemm_nt, and with LayerNorm folding the GELU' epilogue
 # that also emits row dots and the dX GEMM whose epilogue is the LayerNorm backward
-NT_FAMILY = ('gemm_nt', 'gemm_nt_dgelu_stats', 'gemm_nt_lnbwd')
+NT_FAMILY = ('gemm_nt', 'gemm_nt_dgelu_stats', 'gemm_nt_lnbwd', 'gemm_nt_gelu_d', 'gemm_nt_mul')
 
 
 class TimedOps:
@@ -784,7 +784,7 @@ def main():
         intensity = fpl / traffic if traffic else None
         bound = 'hbm' if intensity is not None and intensity < peak / HBM_ACHIEVABLE_TBS else 'mfma'
         hbm_tbs = traffic / avg_s / 1e12 if traffic else None
-        roof = dict(bound=bound, kernel='mbx_gemm_nt / mbx_gemm_nt_dgelu_stats / mbx_gemm_nt_lnbwd -> gemm_nt_pp256_kernel (store, GELU, dGELU epilogues) / gemm_nt_pipe_kernel (residual and LayerNorm-backward epilogues) (bf16 MFMA GEMM, every launch of a step: `launches`)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+        roof = dict(bound=bound, kernel='mbx_gemm_nt / mbx_gemm_nt_gelu_d / mbx_gemm_nt_mul / mbx_gemm_nt_lnbwd -> gemm_nt_pp256_kernel (store, GELU + GELU\' saved, multiply epilogues) / gemm_nt_pipe_kernel (residual and LayerNorm-backward epilogues) (bf16 MFMA GEMM, every launch of a step: `launches`)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                     traffic=traffic, traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt kernels)',
                     traffic_source=('STATIC: ' + os.path.relpath(PMC_TABLE, ROOT) + ' (separate rocprofv3 --pmc passes of this command on this round\'s kernels: '
                                     'FETCH_SIZE x2 + WRITE_SIZE); not measured by this run') if os.path.exists(PMC_TABLE) else None, launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),

@@ -42,7 +42,9 @@ enum mbx_epilogue {
     MBX_EPI_DGELU = 4, /* out_t = acc * gelu_erf'(aux_t)              backward of nn.GELU                  */
     MBX_EPI_LNBWD = 5, /* internal to mbx_gemm_nt_lnbwd (LayerNorm backward as a GEMM epilogue); not accepted by mbx_gemm_nt */
     /* 6, 7, 8: epilogues of rounds 3 / 4 that never had a caller in the default path; removed in round 5 */
-    MBX_EPI_LNBWD_T = 9   /* internal to mbx_gemm_nt_lnbwd_t (MBX_EPI_LNBWD with the gradient residual stream in bf16) */
+    MBX_EPI_LNBWD_T = 9,  /* internal to mbx_gemm_nt_lnbwd_t (MBX_EPI_LNBWD with the gradient residual stream in bf16) */
+    MBX_EPI_GELU_D = 10,  /* internal to mbx_gemm_nt_gelu_d: out2_t = gelu_erf(acc + bias), out_t = gelu_erf'(acc + bias) */
+    MBX_EPI_MULAUX = 11   /* internal to mbx_gemm_nt_mul:    out_t = acc * aux_t */
 };
 
 enum mbx_attn_mode {
@@ -115,6 +117,11 @@ int mbx_fold_norm_weights(const int64_t* desc, int n_desc, int max_n, int max_k,
  * output du (rsum, bias_f enter rounded to bf16: packed-bf16 dot products).  bf16; N % 64 == 0, K % 64 == 0. */
 int mbx_gemm_nt_dgelu_stats(const void* a, const void* w, void* out_t, const void* aux_t, const float* bias_f,
                             const float* rsum, float* part, int M, int N, int K, void* stream);
+/* fc1 + nn.GELU with the DERIVATIVE saved for backward instead of the pre-activation (DSTformer.py:80-81; round 5):
+ * out_g = gelu_erf(a . w^T + bias), out_d = gelu_erf'(a . w^T + bias) (from the fp32 accumulator), both bf16 [M,N]; the backward of the
+ * activation is then mbx_gemm_nt_mul: out = (a . w^T) * aux.  bf16; N >= 256, N % 8 == 0, K % 64 == 0. */
+int mbx_gemm_nt_gelu_d(const void* a, const void* w, const float* bias, void* out_d, void* out_g, int M, int N, int K, void* stream);
+int mbx_gemm_nt_mul(const void* a, const void* w, const void* aux, void* out, int M, int N, int K, void* stream);
 /* rowc[M][4] f32 = {rstd, rstd c1, rstd c2, 0} from part[nb][M][2] (block-major; nb = 2 x heads, or N/64 column blocks) */
 int mbx_lnbwd_rowc(const float* part, int nb, const float* rstd, float* rowc, int M, int C, void* stream);
 /* dx[M,N] f32 = dres [+ extra] + rowc.x (a . w^T) - rowc.y - xhat rowc.z;  dx_t = bf16 copy of dx or NULL.

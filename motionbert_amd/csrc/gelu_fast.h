@@ -52,6 +52,25 @@ __device__ __forceinline__ mbx_f32x2_t gelu_fast_grad2(mbx_f32x2_t u) {
     const mbx_f32x2_t se = {copysignf(e[0], u[0]), copysignf(e[1], u[1])};
     return (u * gauss) * 0.39894228040143267794f + (se * 0.5f + 0.5f);
 }
+// GELU and GELU' of two values at once (the fc1 epilogue that saves the derivative instead of the pre-activation): both from the
+// 7.1.26 parts of gelu_fast_grad2 -- gelu = u (1 + erf) / 2, gelu' = (1 + erf) / 2 + u phi(u).
+__device__ __forceinline__ void gelu_fast_both2(mbx_f32x2_t u, mbx_f32x2_t& gl, mbx_f32x2_t& gr) {
+    const mbx_f32x2_t a = {fabsf(u[0]), fabsf(u[1])};
+    const mbx_f32x2_t den = a * 0.23164189f + 1.0f;
+    const mbx_f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const mbx_f32x2_t w = (u * u) * -0.72134752044448170368f;
+    const mbx_f32x2_t gauss = {__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
+    mbx_f32x2_t poly = t * 1.061405429f + -1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + -0.284496736f;
+    poly = poly * t + 0.254829592f;
+    poly = poly * t;
+    const mbx_f32x2_t e = 1.0f - poly * gauss;
+    const mbx_f32x2_t se = {copysignf(e[0], u[0]), copysignf(e[1], u[1])};
+    const mbx_f32x2_t phi = se * 0.5f + 0.5f;                 // Phi(u)
+    gl = u * phi;
+    gr = (u * gauss) * 0.39894228040143267794f + phi;
+}
 __device__ __forceinline__ float gelu_fast_grad(float u) {
     float e, g;
     erf_parts(u, e, g);

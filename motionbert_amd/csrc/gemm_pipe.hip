@@ -470,7 +470,7 @@ template <int EPI, int NTN, bool FULL>
 __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* er, const float* __restrict__ bias,
                                                  bf16_t* __restrict__ out_t, bf16_t* __restrict__ out2_t, int M, int N,
                                                  int row_base, int col_base, int lane) {
-    static_assert(EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU, "bf16 staging: STORE / GELU only");
+    static_assert(EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU || EPI == MBX_EPI_GELU_D, "bf16 staging: STORE / GELU / GELU_D only");
     const int i = lane & 31, g = lane >> 5;
     const int rr = lane >> 3, cc = (lane & 7) * 8;
     char* er2 = er + EB_TILE;
@@ -500,8 +500,16 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                     if (EPI == MBX_EPI_STORE) {
                         *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     } else {
-                        if (out_t) *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                        const mbx_f32x2_t g0 = gelu_fast2(mbx_f32x2_t{v[0], v[1]}), g1 = gelu_fast2(mbx_f32x2_t{v[2], v[3]});
+                        mbx_f32x2_t g0, g1;
+                        if (EPI == MBX_EPI_GELU_D) {       // the derivative instead of the pre-activation (both from one erf and one Gaussian)
+                            mbx_f32x2_t d0, d1;
+                            gelu_fast_both2(mbx_f32x2_t{v[0], v[1]}, g0, d0);
+                            gelu_fast_both2(mbx_f32x2_t{v[2], v[3]}, g1, d1);
+                            *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(d0[0], d0[1]), pack_bf2(d1[0], d1[1]));
+                        } else {
+                            if (out_t) *reinterpret_cast<uint2*>(er + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                            g0 = gelu_fast2(mbx_f32x2_t{v[0], v[1]}); g1 = gelu_fast2(mbx_f32x2_t{v[2], v[3]});
+                        }
                         *reinterpret_cast<uint2*>(er2 + off) = make_uint2(pack_bf2(g0[0], g0[1]), pack_bf2(g1[0], g1[1]));
                     }
                 }
@@ -511,7 +519,7 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
                 // unconditional (with out_t == nullptr the bytes are stale and never stored): a conditionally assigned array
                 // becomes a stack object -- 64 B of scratch per lane, +41 % HBM writes on the fc1 launches (profiles/r02_pmc_bench.txt)
                 t1[p] = *reinterpret_cast<const uint4*>(er + (p * 8 + rr) * EB_PITCH + cc * 2);
-                if (EPI == MBX_EPI_GELU) t2[p] = *reinterpret_cast<const uint4*>(er2 + (p * 8 + rr) * EB_PITCH + cc * 2);
+                if (EPI != MBX_EPI_STORE) t2[p] = *reinterpret_cast<const uint4*>(er2 + (p * 8 + rr) * EB_PITCH + cc * 2);
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -535,7 +543,8 @@ __device__ __forceinline__ void nt_epilogue_bf16(f32x16_t (&acc)[NTN][4], char* 
 // needs (see "LayerNorm folding" in elementwise.hip): part[n / 64][m] = { sum_n du s[n], sum_n du (u - b'[n]) } over the
 // block's columns, du = the bf16-ROUNDED output (what the dX GEMM will read), s and b' rounded to bf16 (packed-bf16 dot
 // products; see fill_stat_vec in attention.hip for the error budget).  Eight lanes share a row: three DPP steps.
-template <int NTN>
+// MUL: `aux` holds the derivative itself (saved by the MBX_EPI_GELU_D epilogue of fc1's forward): one multiply, no erf, no Gaussian.
+template <int NTN, bool MUL = false>
 __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char* er, bf16_t* __restrict__ out_t,
                                                   const bf16_t* __restrict__ aux, int M, int N, int row_base, int col_base,
                                                   int lane, const float* __restrict__ st_bias = nullptr,
@@ -588,7 +597,7 @@ __device__ __forceinline__ void nt_epilogue_dgelu(f32x16_t (&acc)[NTN][4], char*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float u0 = __uint_as_float(uw[e] << 16), u1 = __uint_as_float(uw[e] & 0xffff0000u);
-                        const mbx_f32x2_t dv_ = mbx_f32x2_t{v[2 * e], v[2 * e + 1]} * gelu_fast_grad2(mbx_f32x2_t{u0, u1});
+                        const mbx_f32x2_t dv_ = mbx_f32x2_t{v[2 * e], v[2 * e + 1]} * (MUL ? mbx_f32x2_t{u0, u1} : gelu_fast_grad2(mbx_f32x2_t{u0, u1}));
                         r[e] = pack_bf2(dv_[0], dv_[1]);
                         if (st_part) {      // packed-bf16 dots (v_dot2c_f32_bf16): du . rsum and du . (u - b')
                             q1 = dot2_bf16(r[e], svp[e], q1);
@@ -622,7 +631,7 @@ __device__ __forceinline__ void nt256_epilogue(f32x16_t (&acc)[2][4], char* smem
     const int row_base = m0 + (wave >> 2) * 128, col_base = n0 + (wave & 3) * 64;
     if constexpr (sizeof(TO) == 4) {      // fp32-class mode (bf16x3): every T-typed tensor is fp32
         nt_epilogue<EPI, 2, TO>(acc, er, bias, out_t, out2_t, out_f, resid, aux, M, N, row_base, col_base, lane, pl_hi, pl_lo);
-    } else if constexpr (EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU) {
+    } else if constexpr (EPI == MBX_EPI_STORE || EPI == MBX_EPI_GELU || EPI == MBX_EPI_GELU_D) {
         if (row_base + 128 <= M && col_base + 64 <= N)
             nt_epilogue_bf16<EPI, 2, true>(acc, er, bias, out_t, out2_t, M, N, row_base, col_base, lane);
         else
@@ -630,6 +639,8 @@ __device__ __forceinline__ void nt256_epilogue(f32x16_t (&acc)[2][4], char* smem
     }
     else if constexpr (EPI == MBX_EPI_DGELU)
         nt_epilogue_dgelu<2>(acc, er, out_t, aux, M, N, row_base, col_base, lane, st_bias, st_rsum, st_part);
+    else if constexpr (EPI == MBX_EPI_MULAUX)
+        nt_epilogue_dgelu<2, true>(acc, er, out_t, aux, M, N, row_base, col_base, lane);
     else
         nt_epilogue<EPI, 2, TO>(acc, er, bias, out_t, out2_t, out_f, resid, aux, M, N, row_base, col_base, lane);
 }
@@ -935,6 +946,8 @@ static int launch_nt256(const void* a, const void* w, const float* bias, int epi
         MBX_Q_CASE(MBX_EPI_RESID)
         MBX_Q_CASE(MBX_EPI_TANH)
         MBX_Q_CASE(MBX_EPI_DGELU)
+        MBX_Q_CASE(MBX_EPI_GELU_D)
+        MBX_Q_CASE(MBX_EPI_MULAUX)
         default: return mbx_set_error("gemm_nt: unknown epilogue %d", epi);
     }
 #undef MBX_Q_CASE
@@ -1020,6 +1033,22 @@ extern "C" int mbx_gemm_nt_dgelu_stats(const void* a, const void* w, void* out_t
     MBX_CHECK_ARG(a && w && out_t && aux_t && bias_f && rsum && part, "gemm_nt_dgelu_stats: null pointer");
     MBX_CHECK_ARG(M > 0 && N > 0 && N % 64 == 0 && K > 0 && K % 64 == 0, "gemm_nt_dgelu_stats: bad shape M=%d N=%d K=%d (N %% 64, K %% 64)", M, N, K);
     return launch_nt256(a, w, nullptr, MBX_EPI_DGELU, out_t, nullptr, nullptr, nullptr, aux_t, M, N, K, (hipStream_t)stream, bias_f, rsum, part);
+}
+
+// ---- round 5: the activation's derivative saved instead of the pre-activation ---------------------------
+// fc1 + GELU: out_g = gelu(a . w^T + bias), out_d = gelu'(a . w^T + bias) taken from the fp32 accumulator; the backward epilogue is then
+// ONE multiply (mbx_gemm_nt_mul).  Possible since the row-owner LayerNorm-backward GEMM takes its row means itself: the GELU' epilogue no
+// longer has to produce the dot of du with the pre-activation.
+extern "C" int mbx_gemm_nt_gelu_d(const void* a, const void* w, const float* bias, void* out_d, void* out_g, int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(a && w && out_d && out_g, "gemm_nt_gelu_d: null pointer");
+    MBX_CHECK_ARG(M > 0 && N >= 256 && N % 8 == 0 && K >= 64 && K % 64 == 0, "gemm_nt_gelu_d: bad shape M=%d N=%d (>= 256, %% 8) K=%d (%% 64)", M, N, K);
+    return launch_nt256(a, w, bias, MBX_EPI_GELU_D, out_d, out_g, nullptr, nullptr, nullptr, M, N, K, (hipStream_t)stream);
+}
+// out = (a . w^T) * aux  (aux = the saved derivative)
+extern "C" int mbx_gemm_nt_mul(const void* a, const void* w, const void* aux, void* out, int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(a && w && aux && out, "gemm_nt_mul: null pointer");
+    MBX_CHECK_ARG(M > 0 && N >= 256 && N % 8 == 0 && K >= 64 && K % 64 == 0, "gemm_nt_mul: bad shape M=%d N=%d (>= 256, %% 8) K=%d (%% 64)", M, N, K);
+    return launch_nt256(a, w, nullptr, MBX_EPI_MULAUX, out, nullptr, nullptr, nullptr, aux, M, N, K, (hipStream_t)stream);
 }
 // dx = dres [+ extra] + rstd (dy . Wt' - c1 - xhat c2)  with rowc[m] = {rstd, rstd c1, rstd c2, -};  dx_t = bf16 copy (or NULL)
 extern "C" int mbx_gemm_nt_lnbwd(const void* a, const void* w, const void* xhat, const float* rowc, const float* dres,

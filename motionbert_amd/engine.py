@@ -172,6 +172,10 @@ class Engine:
         # sub-layer of a Block (fp32 out, the other block's gradient added) keeps the tile kernel.  MBX_ROWS_LNBWD=0: the A/B switch.
         self.rows_lnbwd = (os.environ.get('MBX_ROWS_LNBWD', '1') == '1' and bool(getattr(ops, 'can_rows_lnbwd', lambda *_: False)(tdtype, cfg)))
         self.Pn: Dict[str, torch.Tensor] = {}       # transposed folded weights in the fragment order of mbx_rows_lnbwd_t
+        # Round 5: with the row means taken by that kernel the GELU' epilogue no longer has to produce the dot of
+        # du with the pre-activation, so fc1's forward epilogue saves gelu'(u) -- taken from the fp32 accumulator -- INSTEAD of u (same
+        # bytes) and the backward epilogue is one multiply (mbx_gemm_nt_gelu_d / mbx_gemm_nt_mul).  MBX_GELU_D=0: the A/B switch.
+        self.gelu_d = (os.environ.get('MBX_GELU_D', '1') == '1' and self.rows_lnbwd and bool(getattr(ops, 'can_gelu_d', lambda *_: False)(tdtype, cfg)))
         # no-grad sequencing of a Block (decided per forward): raw-operand LayerNorm + fused MLP, see the module docstring
         self.rawln = False
         self.rawln_allowed = os.environ.get('MBX_RAWLN', '1') == '1'      # A/B switch: 0 = the training sequencing without saves
@@ -514,14 +518,21 @@ class Engine:
         mlp_drop = dm is not None and dm[0] > 0
         # u only feeds GELU' in backward; g is only fc2's operand (and the weight gradient's) unless the MLP dropout touches it first
         u, g = (self._t(M, cfg.hidden) if need_grad else None), (self._t(M, cfg.hidden) if mlp_drop else self._op(M, cfg.hidden))
-        ops.gemm_nt(xn, self.Wn[f'{pre}.{mlp}.fc1'], self.Bf[f'{pre}.{mlp}.fc1'] if self.fold else P[f'{pre}.{mlp}.fc1.bias'],
-                    EPI_GELU, out_t=u, out2_t=g)
+        # the derivative instead of the pre-activation where backward will run the row-owner tail (every MLP of a Block does: never the
+        # first sub-layer, so bf16 gradient in and out and no second summand)
+        save_d = bool(need_grad and self.fold and self.gelu_d and self.gstream_allowed and not self.recompute and not mlp_drop
+                      and f'{pre}.{mlp}.fc1' in self.Pn)
+        if save_d:
+            ops.gemm_nt_gelu_d(xn, self.Wn[f'{pre}.{mlp}.fc1'], self.Bf[f'{pre}.{mlp}.fc1'], u, g)
+        else:
+            ops.gemm_nt(xn, self.Wn[f'{pre}.{mlp}.fc1'], self.Bf[f'{pre}.{mlp}.fc1'] if self.fold else P[f'{pre}.{mlp}.fc1.bias'],
+                        EPI_GELU, out_t=u, out2_t=g)
         if dm is not None and dm[0] > 0:                      # MLP drop after the activation (DSTformer.py:82)
             ops.dropout(g, g, dm[0], dm[2])
         g = self._mm(g)
         y, ln_y = self._resid_gemm(g, f'{pre}.{mlp}.fc2', x, dm, pre, nxt)
         if self.fold:
-            sv = dict(x=None, mean=None, rstd=rstd, xn=xn, u=u, g=None if self.recompute else g, dm=dm) if need_grad else None
+            sv = dict(x=None, mean=None, rstd=rstd, xn=xn, u=None if save_d else u, d=u if save_d else None, g=None if self.recompute else g, dm=dm) if need_grad else None
         else:
             sv = dict(x=x, mean=mean, rstd=rstd, xn=None if self.recompute else xn, u=u, g=None if self.recompute else g, dm=dm) if need_grad else None
         return y, sv, ln_y
@@ -737,6 +748,13 @@ class Engine:
         del g
         if self.fold:
             lin = f'{pre}.{mlp}.fc1'
+            if sv.get('d') is not None:                           # forward saved gelu'(u): one multiply, then the row-owner tail
+                if dy_t is None:
+                    dy_t = dy.to(self.T)
+                if not self._rows_tail_ok(lin, dy_t, extra, need_t):
+                    raise RuntimeError(f'{lin}: the derivative was saved for the row-owner LayerNorm backward, which cannot run here')
+                ops.gemm_nt_mul(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], sv['d'], du)
+                return self._fold_tail(du, None, sv, lin, f'{pre}.{norm}', dy, dy_t, extra, need_t)
             if self._rows_tail_ok(lin, dy_t, extra, need_t):      # the consumer takes its row means itself: plain GELU' epilogue
                 ops.gemm_nt(dy_t, self.Wt[f'{pre}.{mlp}.fc2'], None, EPI_DGELU, out_t=du, aux_t=sv['u'])
                 return self._fold_tail(du, None, sv, lin, f'{pre}.{norm}', dy, dy_t, extra, need_t)

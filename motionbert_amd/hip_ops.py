@@ -38,6 +38,8 @@ SIGNATURES = {
     'mbx_gemm_tn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mbx_fold_norm_weights': (_i, [_i64p, _i, _i, _i, _vp]),
     'mbx_gemm_nt_dgelu_stats': (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
+    'mbx_gemm_nt_gelu_d': (_i, [_vp] * 5 + [_i, _i, _i, _vp]),
+    'mbx_gemm_nt_mul': (_i, [_vp] * 4 + [_i, _i, _i, _vp]),
     'mbx_lnbwd_rowc': (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     'mbx_gemm_nt_lnbwd': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
     'mbx_gemm_nt_lnbwd_t': (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
@@ -259,6 +261,21 @@ class HipOps:
         M, K = a_t.shape
         N = w_t.shape[0]
         self._ck(self.lib.mbx_gemm_nt_dgelu_stats(_p(a_t), _p(w_t), _p(out_t), _p(aux_t), _p(bias_f), _p(rsum), _p(part), M, N, K, self._stream()))
+
+    # round 5: fc1 + GELU with the derivative saved for backward instead of the pre-activation, and the one-multiply backward epilogue
+    @staticmethod
+    def can_gelu_d(tdtype, cfg) -> bool:
+        return tdtype == torch.bfloat16 and cfg.hidden >= 256 and cfg.hidden % 8 == 0 and cfg.C % 64 == 0
+
+    def gemm_nt_gelu_d(self, a_t, w_t, bias, out_d, out_g):
+        M, K = a_t.shape
+        N = w_t.shape[0]
+        self._ck(self.lib.mbx_gemm_nt_gelu_d(_p(a_t), _p(w_t), _p(bias), _p(out_d), _p(out_g), M, N, K, self._stream()))
+
+    def gemm_nt_mul(self, a_t, w_t, aux_t, out_t):
+        M, K = a_t.shape
+        N = w_t.shape[0]
+        self._ck(self.lib.mbx_gemm_nt_mul(_p(a_t), _p(w_t), _p(aux_t), _p(out_t), M, N, K, self._stream()))
 
     def attn_bwd_stats(self, qkv, o, do, lse, dqkv, bias_f, rsum, part, B, T, J, H, scale, mode):
         hd = o.shape[-1] // H

@@ -119,11 +119,13 @@ class _DSTformerFn(torch.autograd.Function):
         grad_enabled, grad_sync = grad_sync
         need_grad = grad_enabled and any(ctx.needs_input_grad[6:])
         P = dict(zip(names, params))
+        precision, gelu_d = (precision[:-3], False) if precision.endswith('+nd') else (precision, True)
         precision, fold = (precision[:-3], False) if precision.endswith('+nf') else (precision, True)
         precision, recompute = (precision[:-2], True) if precision.endswith('+r') else (precision, False)
         eng = Engine(ops, cfg, P, _DTYPES[precision], x3=precision == 'bf16x3', drop_seed=drop_seed)
         eng.recompute = recompute
         eng.fold = eng.fold and fold
+        eng.gelu_d = eng.gelu_d and gelu_d
         with _device_of(x):
             tta = None
             if isinstance(return_rep, tuple) and return_rep[0] == 'tta':
@@ -232,7 +234,7 @@ def run(ops, model, x, return_rep=False, grad_sync=None):
         drop_seed = getattr(model, '_drop_seed', None)
         if drop_seed is None:
             drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    return _DSTformerFn.apply(ops, cfg, names, (model.precision + ('+r' if getattr(model, 'recompute', False) else '') + ('' if getattr(model, 'fold_ln', True) else '+nf'), drop_seed), return_rep, (torch.is_grad_enabled(), grad_sync), x, *params)
+    return _DSTformerFn.apply(ops, cfg, names, (model.precision + ('+r' if getattr(model, 'recompute', False) else '') + ('' if getattr(model, 'fold_ln', True) else '+nf') + ('' if getattr(model, 'gelu_d', True) else '+nd'), drop_seed), return_rep, (torch.is_grad_enabled(), grad_sync), x, *params)
 
 
 class DSTformer(nn.Module):
@@ -258,6 +260,11 @@ class DSTformer(nn.Module):
         #: backward runs as the epilogue of the dX GEMM (engine.py, include/mbx.h).  False selects the plain sequencing (the A/B
         #: switch of the measurements; the fp32-class modes and training with dropout use the plain sequencing anyway).
         self.fold_ln = True
+        #: bf16 training: fc1's epilogue saves gelu'(u) (from the fp32 accumulator) instead of the pre-activation wherever the row-owner
+        #: LayerNorm-backward GEMM follows in backward; False keeps the pre-activation and the GELU' epilogue (the A/B switch, and what
+        #: `recompute` uses anyway).  The two forward epilogues use different erf approximations (both ~1e-7): outputs agree to bf16
+        #: rounding, not bit for bit.
+        self.gelu_d = True
         self.joints_embed = nn.Linear(dim_in, dim_feat)
         self.pos_drop = nn.Dropout(p=drop_rate)
         dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]

@@ -84,6 +84,23 @@ class MockOps:
         rsum, bias_f = self._stat_vec(rsum, out_t.dtype), self._stat_vec(bias_f, out_t.dtype)
         part.copy_(torch.stack([(d * rsum).reshape(M, N // 64, 64).sum(-1), (d * (u - bias_f)).reshape(M, N // 64, 64).sum(-1)], -1).transpose(0, 1))
 
+    fuse_gelu_d = True        # tests switch it off to exercise the GELU' epilogue from the saved pre-activation
+
+    def can_gelu_d(self, tdtype, cfg) -> bool:
+        return bool(self.fuse_gelu_d)
+
+    def gemm_nt_gelu_d(self, a_t, w_t, bias, out_d, out_g):
+        """mbx_gemm_nt_gelu_d: out_g = gelu(a . w^T + bias), out_d = gelu'(a . w^T + bias), both from the fp32 product."""
+        self._log('gemm_nt.gelu_d')
+        u = a_t.float() @ w_t.float().t() + (bias if bias is not None else 0.)
+        out_g.copy_(F.gelu(u).to(out_g.dtype))
+        out_d.copy_(_gelu_grad(u).to(out_d.dtype))
+
+    def gemm_nt_mul(self, a_t, w_t, aux_t, out_t):
+        """mbx_gemm_nt_mul: out = (a . w^T) * aux."""
+        self._log('gemm_nt.mul')
+        out_t.copy_(((a_t.float() @ w_t.float().t()) * aux_t.float()).to(out_t.dtype))
+
     def attn_bwd_stats(self, qkv, o, do, lse, dqkv, bias_f, rsum, part, B, T, J, H, scale, mode):
         """attn_bwd + part[2 h + role][m] = { sum d rsum, sum d (qkv - bias_f) } of the rounded dqkv over the head's q columns
         (role 0) and over its k and v columns (role 1)."""

@@ -9,7 +9,7 @@ feeds").  Tolerances: fp32 outputs of bf16 operands 2e-5 (only the summation ord
 import pytest
 import torch
 
-from motionbert_amd.engine import MODE_SPATIAL, MODE_TEMPORAL
+from motionbert_amd.engine import EPI_DGELU, EPI_GELU, MODE_SPATIAL, MODE_TEMPORAL
 from tests.helpers import build_model, load_golden
 from tests.mock_ops import MockOps
 from tests.test_gpu_kernels import DEV, REPORT, check, rnd
@@ -97,6 +97,31 @@ def test_gemm_nt_dgelu_stats(ops, M, N, K):
     own = torch.stack([(d * rb).reshape(M, N // 64, 64).sum(-1), (d * (u.float() - bb)).reshape(M, N // 64, 64).sum(-1)], -1).transpose(0, 1)
     check(f'gemm_nt_dgelu_stats.part.{tag}', g[1], own, 1e-4)
     check(f'gemm_nt_dgelu_stats.part_vs_ref.{tag}', g[1], r[1], 2e-2)
+
+
+@pytest.mark.parametrize('M,N,K', [(4131, 1024, 512), (1000, 256, 128), (264384 // 16, 1024, 512), (300, 512, 64), (257, 264, 64)])
+def test_gemm_nt_gelu_d_and_mul(ops, M, N, K):
+    """fc1 + GELU saving the derivative (mbx_gemm_nt_gelu_d) and the one-multiply backward epilogue (mbx_gemm_nt_mul), against the torch
+    restatement; the pair against the GELU' epilogue that works from the saved pre-activation (same gradient up to bf16 rounding)."""
+    a, w, bias = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, dtype=BF, scale=0.08), rnd(N, seed=3, scale=0.3)
+    mk = lambda: [torch.full((M, N), 7.0, device=DEV, dtype=BF), torch.full((M, N), 7.0, device=DEV, dtype=BF)]
+    g, r = mk(), mk()
+    ops.gemm_nt_gelu_d(a, w, bias, g[0], g[1])
+    MockOps().gemm_nt_gelu_d(a, w, bias, r[0], r[1])
+    tag = f'M{M}.N{N}.K{K}'
+    check(f'gemm_nt_gelu_d.d.{tag}', g[0], r[0], 4e-3)
+    check(f'gemm_nt_gelu_d.g.{tag}', g[1], r[1], 4e-3)
+    dy, w2 = rnd(M, 64, seed=4, dtype=BF), rnd(N, 64, seed=5, dtype=BF, scale=0.1)
+    du, du_r = torch.full((M, N), 7.0, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt_mul(dy, w2, g[0], du)
+    MockOps().gemm_nt_mul(dy, w2, g[0], du_r)
+    check(f'gemm_nt_mul.{tag}', du, du_r, 4e-3)
+    # the old pair: pre-activation saved, GELU' in the backward epilogue
+    u, g2, du_old = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(a, w, bias, EPI_GELU, out_t=u, out2_t=g2)
+    assert torch.equal(g2, g[1]) or float((g2.float() - g[1].float()).abs().max()) < 0.04      # two erf approximations, both far below bf16 resolution
+    ops.gemm_nt(dy, w2, None, EPI_DGELU, out_t=du_old, aux_t=u)
+    check(f'gemm_nt_mul.vs_dgelu.{tag}', du, du_old, 1.2e-2)
 
 
 @pytest.mark.parametrize('hd', [32, 64])

@@ -540,6 +540,7 @@ def test_recompute_mode_matches_normal_mode():
     model = model.to(DEV)
     x = make_input(2, 81, 17, 33).to(DEV)
     cot = torch.randn(2, 81, 17, 3, generator=torch.Generator().manual_seed(34)).to(DEV)
+    model.gelu_d = False      # (round 5) the low-memory mode keeps the pre-activation: compare it with the normal mode that does, too
     for precision, tol in (('fp32', 1e-5), ('bf16x3', 1e-5), ('bf16', TOL_BF16_GRAD / 4)):
         model.precision = precision
         res = []
@@ -554,6 +555,32 @@ def test_recompute_mode_matches_normal_mode():
         REPORT[f'recompute_vs_normal.{precision}'] = rel
         assert rel < tol, (precision, rel)
     model.recompute = False
+
+
+def test_saved_gelu_derivative_against_saved_preactivation():
+    """bf16 training saves gelu'(u) from the fp32 accumulator instead of u (model.gelu_d, round 5).  Against the pre-activation mode on
+    the same weights and input: the two forward epilogues differ in the erf approximation only, so the outputs agree to the bf16 mode's
+    own noise; both gradients are then measured against the SAME fp32 run -- the new mode must not be further from it than the gate
+    that bounds the bf16 mode itself, nor noticeably further than the old one."""
+    model = build_model(FULL, seed=41)
+    trained_like(model, 42)
+    model = model.to(DEV)
+    x = make_input(2, 81, 17, 43).to(DEV)
+    cot = torch.randn(2, 81, 17, 3, generator=torch.Generator().manual_seed(44)).to(DEV)
+    res = {}
+    for tag, precision, gd in (('fp32', 'fp32', True), ('d', 'bf16', True), ('u', 'bf16', False)):
+        model.precision, model.gelu_d = precision, gd
+        model.zero_grad(set_to_none=True)
+        out = model(x)
+        (out * cot).sum().backward()
+        res[tag] = (out.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]))
+    model.gelu_d = True
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    eo_d, eo_u = rel(res['d'][0], res['fp32'][0]), rel(res['u'][0], res['fp32'][0])
+    eg_d, eg_u = rel(res['d'][1], res['fp32'][1]), rel(res['u'][1], res['fp32'][1])
+    REPORT['gelu_d.out_err'], REPORT['gelu_u.out_err'], REPORT['gelu_d.grad_err'], REPORT['gelu_u.grad_err'] = eo_d, eo_u, eg_d, eg_u
+    assert eg_d < TOL_BF16_GRAD and eg_u < TOL_BF16_GRAD, (eg_d, eg_u)
+    assert eg_d < 1.25 * eg_u + 1e-3 and eo_d < 1.25 * eo_u + 1e-3, (eo_d, eo_u, eg_d, eg_u)
 
 
 @pytest.mark.parametrize('recompute', [False, True])

@@ -66,6 +66,9 @@ def test_engine_fp32_matches_reference_gradients(name, fold, rows):
     assert ops.calls.count('rows_lnbwd_t') == ops.calls.count('rows_n_pack') - (2 * depth if rw else 0) == (6 * depth if rw else 0)
     # forward: 8 residual GEMMs per level
     assert ops.calls.count('gemm_nt.2') == 8 * depth
+    # the MLPs of a Block (4 per level) save gelu'(u) instead of u where the row-owner tail follows: one-multiply backward epilogue
+    assert ops.calls.count('gemm_nt.gelu_d') == ops.calls.count('gemm_nt.mul') == (4 * depth if rw else 0)
+    assert ops.calls.count('gemm_nt.1') == (0 if rw else 4 * depth)      # EPI_GELU
 
 
 def test_engine_representation_path(golden_dir):
