@@ -303,7 +303,10 @@ class Engine:
             self.Wn.update(fn)
             self.Wt.update(ft)
             if need_grad and self.rows_lnbwd and self.gstream_allowed:
-                self.Pn = {lin: ops.rows_n_pack(ft[lin]) for lin, _ in pairs}
+                # (not for the first sub-layer of a Block: its LayerNorm backward leaves the Block in fp32 and adds the other stream's
+                # gradient -- the tile kernel's epilogue)
+                first = {f'{stream}.{i}.{ORDER[kind][0][2]}.qkv' for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')) for i in range(cfg.depth)}
+                self.Pn = {lin: ops.rows_n_pack(ft[lin]) for lin, _ in pairs if lin not in first}
             if self.rawln:
                 for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')):
                     for i in range(cfg.depth):
