@@ -348,6 +348,13 @@ size_t mbx_rows_n_pack_bytes(int K);
 int mbx_rows_n_pack(const void* w, void* packed, int K, void* stream);
 int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* xhat, const float* rstd, const void* dres_t, void* dx_t, int M,
                      int N, int K, void* stream);
+/* The FORWARD residual GEMM of a sub-layer that is followed by a LayerNorm, on the same row-owner shape (proj / fc2 + residual,
+ * DSTformer.py:241-249, and the next norm1 / norm2): y = resid + a . w^T + bias (fp32 [M,512]); xhat = (y - mean(y)) rstd(y) (bf16 [M,512],
+ * the plain normalisation: gamma and beta live in the folded weights of the Linear the LayerNorm feeds), mean / rstd fp32 [M] (two-pass
+ * statistics of the fp32 rows, eps inside the square root).  packed = mbx_rows_n_pack of w [512,K].  bf16; N == 512, K >= 512,
+ * K % 256 == 0, M * 2048 < 2^32. */
+int mbx_rows_resid_ln(const void* a, const void* packed, const float* bias, const float* resid, float* y, void* xhat, float* mean,
+                      float* rstd, float eps, int M, int N, int K, void* stream);
 
 /* ---- measurement aid (bench.py `roofline.sustained_mfma_tflops`; not part of the model) --------------------------------------------
  * The bf16 MFMA rate the part sustains under its power cap with nothing but v_mfma_f32_32x32x16_bf16 in the loop (pseudo-random

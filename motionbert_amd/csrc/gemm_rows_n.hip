@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
 #pragma unroll
     for (int r4 = 0; r4 < 8; ++r4) xoff[r4] = (unsigned)min(mw + 4 * r4 + xr, M - 1) * (RN_N * 2) + xp * 16;
 #define RN_XLD(n_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr_[n_]) : "v"(xoff[(n_) & 7]), "s"(xhat), "n"(((n_) >> 3) * 256) : "memory")
-#define RN_TRIP(LAST_)                                                                                               \
+#define RN_TRIP(LAST_, XPF_)                                                                                             \
     {                                                                                                                \
         const char* const apn = ap + 512;                   /* where the tokens of the next trip's first half are */                   \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                              \
@@ -117,8 +117,10 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             const char* const n4 = wpk + (size_t)min(q + 4, nstages - 1) * RN_STAGE;                                 \
             _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                         \
                 if (k == 32 - PF) {                                                                                  \
-                    if (LAST_) { if (u == 0) rn_vmwait<23>(); else if (u == 1) rn_vmwait<27>(); else if (u < 4) rn_vmwait<31>();      \
+                    if (LAST_ && XPF_) { if (u == 0) rn_vmwait<23>(); else if (u == 1) rn_vmwait<27>(); else if (u < 4) rn_vmwait<31>(); \
                                  else if (u == 4) rn_vmwait<30>(); else if (u == 5) rn_vmwait<28>(); else rn_vmwait<26>(); }      \
+                    else if (LAST_) { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else if (u < 4) rn_vmwait<21>(); \
+                                 else if (u == 4) rn_vmwait<20>(); else if (u == 5) rn_vmwait<18>(); else rn_vmwait<16>(); }      \
                     else { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else rn_vmwait<21>(); }    \
                     __builtin_amdgcn_sched_barrier(0);                                                               \
                     __builtin_amdgcn_s_barrier();                                                                    \
@@ -135,15 +137,15 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
                    compiler, which hands it to something else -- and the load lands in it later) */                                     \
                 if (k == 25) { if (u < 4) RN_TOK(tok[(2 * (u + 4)) & 15], 32 * (2 * (u + 4))); else if (!LAST_) RN_TOKN(tok[(2 * (u + 4)) & 15], 32 * (2 * (u - 4))); } \
                 if (k == 29) { if (u < 4) RN_TOK(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u + 4) + 1)); else if (!LAST_) RN_TOKN(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u - 4) + 1)); } \
-                if (LAST_ && k >= 24 && !(k & 1)) RN_XLD(4 * u + ((k - 24) >> 1));                                   \
+                if (LAST_ && XPF_ && k >= 24 && !(k & 1)) RN_XLD(4 * u + ((k - 24) >> 1));                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                                   \
             }                                                                                                        \
         }                                                                                                            \
         ap += 512;                                                                                                   \
     }
     int q0 = 0;
-    for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false)
-    RN_TRIP(true)
+    for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, true)
+    RN_TRIP(true, true)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the re-read tail stages, the over-read tokens and xhat have landed
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring: 32 KiB of it per wave are buffers now
 #pragma unroll
@@ -241,6 +243,163 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     }
 }
 
+// ---- the same product as the FORWARD residual GEMM of a sub-layer that is followed by a LayerNorm (round 5):
+//     y    = resid + a . w^T + bias                      fp32 [M, 512]   (proj / fc2 + residual, DSTformer.py:241-249)
+//     xhat = (y - mean(y)) rstd(y)                       bf16 [M, 512]   (the next sub-layer's LayerNorm, plain normalisation: gamma and
+//                                                                         beta live in the folded weights of the Linear it feeds)
+// A wave owns whole rows, so the statistics of LayerNorm come from its own registers (two passes over the 256 accumulators, the
+// arithmetic of ln_fwd_row in elementwise.hip) and the stand-alone LayerNorm launch -- which re-reads y from HBM -- disappears.
+// The tile kernel could not do this without a reduction across its four column tiles (round 3 / 4: built, slower, removed).
+// Epilogue: the wave's 32 KiB of the ring are two 16-KiB buffers for one 128-column
+// quarter of resid each (fp32, by LDS-DMA, double-buffered: a row takes 512 bytes, its 16-byte piece p sits at slot p ^ row); y is
+// written over the resid it was made from, read back row-major and stored as 512-byte row segments while the accumulators keep y;
+// then mean and rstd, then xhat through the fifth 8-KiB buffer exactly as dx leaves the LayerNorm-backward kernel above.
+__global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* __restrict__ a, const char* __restrict__ wpk,
+                                                                const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                float* __restrict__ y, bf16_t* __restrict__ xhat_o,
+                                                                float* __restrict__ mean_o, float* __restrict__ rstd_o, float eps, int M, int K) {
+    constexpr int PF = 5;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    const int mw = blockIdx.x * RN_BM + 32 * wave;
+    const unsigned fr = (unsigned)(uintptr_t)(const lds_void_t*)ring + lane * 16;
+    const unsigned wvo = wave * 1024 + lane * 16;
+    const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
+    const unsigned dlu = __builtin_amdgcn_readfirstlane(dl);
+    const int nstages = K / 32;
+    const char* ap = reinterpret_cast<const char*>(a + (size_t)min(mw + i, M - 1) * K + 8 * g);
+    // the wave's copy of the bias (8 floats per lane), requested first -- the oldest vector memory operations of the kernel, so no
+    // counted wait below changes -- and parked in the wave's fifth buffer after the loop (the wait there carries the dependence)
+    u32x4_t bq0, bq1;
+    {
+        const float* const bp = bias + lane * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq0) : "v"(bp) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bq1) : "v"(bp) : "memory");
+    }
+    u32x4_t tok[16];
+    RN_TOK(tok[0], 0); RN_TOK(tok[1], 32); RN_TOK(tok[2], 64); RN_TOK(tok[3], 96);
+    RN_TOK(tok[4], 128); RN_TOK(tok[5], 160); RN_TOK(tok[6], 192); RN_TOK(tok[7], 224);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) RN_ISSUE(q, j);
+    RN_ISSUE(3, 0);
+    RN_ISSUE(3, 1);
+    f32x16_t acc[16];                              // acc[nt][4 qq + e] = out[row i][32 nt + 8 qq + 4 g + e]
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        asm volatile("" : "+a"(acc[t]));
+    }
+    rn_vmwait<18>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4_t fb[8];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
+#undef RN_XLD
+#define RN_XLD(n_) ((void)0)
+    int q0 = 0;
+    for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
+    RN_TRIP(true, false)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bq0), "+v"(bq1) : : "memory");
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
+#pragma unroll
+    for (int t = 0; t < 16; ++t) MFMA_PAD_A(acc[t]);
+
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, i_e = lane_e & 31, g_e = lane_e >> 5, xr_e = lane_e >> 4, xp_e = lane_e & 15;
+    char* const eb = ring + wave * 32768;
+    char* const bx = ring + RN_RING + wave * 8192;
+    const unsigned ebl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 32768);
+    // DMA / read-out instruction d moves rows 2 d, 2 d + 1 of a quarter: lane l = slot l & 31 of row rl = 2 d + (l >> 5), i.e. piece
+    // (l & 31) ^ rl of that row; the same byte offset addresses resid and y
+    unsigned doff[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        const int rl = 2 * d + g_e;
+        doff[d] = (unsigned)min(mw + rl, M - 1) * (RN_N * 4) + ((i_e ^ rl) << 4);
+    }
+#define RN_RDMA(j_, b_) _Pragma("unroll") for (int d_ = 0; d_ < 16; ++d_)                                             \
+        glds16_s(reinterpret_cast<const char*>(resid) + (j_) * 512, doff[d_], ebl + (b_) * 16384 + d_ * 1024)
+    RN_RDMA(0, 0);
+    RN_RDMA(1, 1);
+    *reinterpret_cast<u32x4_t*>(bx + lane_e * 32) = bq0;              // bias[8 lane .. 8 lane + 7]: read below by every lane that holds those columns
+    *reinterpret_cast<u32x4_t*>(bx + lane_e * 32 + 16) = bq1;
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // vector memory operations younger than the DMA of quarter j: [the stores of quarter j - 1 (16)] + the DMA of quarter j + 1 (16)
+        if (j == 0 || j == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        char* const buf = eb + (j & 1) * 16384;
+#pragma unroll
+        for (int ntl = 0; ntl < 4; ++ntl) {
+            f32x16_t t = acc[4 * j + ntl];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                float4* const p = reinterpret_cast<float4*>(buf + i_e * 512 + (((8 * ntl + 2 * qq + g_e) ^ i_e) << 4));
+                const float4 r = *p, b = *reinterpret_cast<const float4*>(bx + (32 * (4 * j + ntl) + 8 * qq + 4 * g_e) * 4);
+                t[4 * qq] += r.x + b.x; t[4 * qq + 1] += r.y + b.y; t[4 * qq + 2] += r.z + b.z; t[4 * qq + 3] += r.w + b.w;
+                *p = make_float4(t[4 * qq], t[4 * qq + 1], t[4 * qq + 2], t[4 * qq + 3]);      // y over the resid it was made from
+                s1 += (t[4 * qq] + t[4 * qq + 1]) + (t[4 * qq + 2] + t[4 * qq + 3]);
+            }
+            acc[4 * j + ntl] = t;                                     // the accumulators keep y for the statistics and xhat
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const float4 v = *reinterpret_cast<const float4*>(buf + d * 1024 + lane_e * 16);
+            // (rows past M carry row M - 1's values -- every load is clamped -- and are stored onto row M - 1: identical bytes, and every
+            // wave issues the same number of vector memory instructions, which the counted waits depend on)
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(y) + doff[d] + j * 512) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the buffer has been read out
+        if (j == 0) { RN_RDMA(2, 0); } else if (j == 1) { RN_RDMA(3, 1); }
+    }
+    // LayerNorm statistics of the 512 values of row i (lanes i and i + 32 hold its halves): two passes, as ln_fwd_row
+    const float mu = wave_halves<WaveAdd>(s1) * (1.0f / (float)RN_N);
+    float s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+        const f32x16_t t = acc[nt];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float c = t[e] - mu; s2 = fmaf(c, c, s2); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const float rs = 1.0f / sqrtf(wave_halves<WaveAdd>(s2) * (1.0f / (float)RN_N) + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int ntl = 0; ntl < 4; ++ntl) {
+            const f32x16_t t = acc[4 * j + ntl];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int off = i_e * 256 + (((ntl * 4 + qq) ^ (i_e & 15)) << 4) + 8 * g_e;
+                *reinterpret_cast<uint2*>(bx + off) = make_uint2(pack_bf2((t[4 * qq] - mu) * rs, (t[4 * qq + 1] - mu) * rs),
+                                                                 pack_bf2((t[4 * qq + 2] - mu) * rs, (t[4 * qq + 3] - mu) * rs));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r4 = 0; r4 < 8; ++r4) {
+            const int rl = 4 * r4 + xr_e;
+            const uint4 v = *reinterpret_cast<const uint4*>(bx + r4 * 1024 + lane_e * 16);
+            *reinterpret_cast<uint4*>(xhat_o + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp_e ^ (rl & 15)) << 3)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (g_e == 0 && mw + i_e < M) {
+        mean_o[mw + i_e] = mu;
+        rstd_o[mw + i_e] = rs;
+    }
+}
+
 // ---- C ABI -------------------------------------------------------------------------------------------------------------------
 extern "C" size_t mbx_rows_n_pack_bytes(int K) { return (size_t)RN_N * K * sizeof(bf16_t); }
 
@@ -262,5 +421,17 @@ extern "C" int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* 
     hipLaunchKernelGGL(rows_n_lnbwd_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)dy,
                        (const char*)packed, (const bf16_t*)xhat, rstd, (const bf16_t*)dres_t, (bf16_t*)dx_t, M, K);
     MBX_LAUNCH_CHECK("rows_lnbwd_t");
+    return 0;
+}
+
+extern "C" int mbx_rows_resid_ln(const void* a, const void* packed, const float* bias, const float* resid, float* y, void* xhat,
+                                 float* mean, float* rstd, float eps, int M, int N, int K, void* stream) {
+    MBX_CHECK_ARG(a && packed && bias && resid && y && xhat && mean && rstd, "rows_resid_ln: null pointer");
+    MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 512 && K % 256 == 0, "rows_resid_ln: bad shape M=%d N=%d (512) K=%d (%% 256, >= 512)", M, N, K);
+    MBX_CHECK_ARG((size_t)M * RN_N * 4 < ((size_t)1 << 32), "rows_resid_ln: M=%d rows of 2 KiB exceed the 32-bit row offsets of the kernel", M);
+    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_resid_ln_kernel), RN_RING + 4 * 8192, "rows_resid_ln")) return 1;
+    hipLaunchKernelGGL(rows_n_resid_ln_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)a,
+                       (const char*)packed, bias, resid, y, (bf16_t*)xhat, mean, rstd, eps, M, K);
+    MBX_LAUNCH_CHECK("rows_resid_ln");
     return 0;
 }

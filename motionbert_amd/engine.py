@@ -172,6 +172,12 @@ class Engine:
         # sub-layer of a Block (fp32 out, the other block's gradient added) keeps the tile kernel.  MBX_ROWS_LNBWD=0: the A/B switch.
         self.rows_lnbwd = (os.environ.get('MBX_ROWS_LNBWD', '1') == '1' and bool(getattr(ops, 'can_rows_lnbwd', lambda *_: False)(tdtype, cfg)))
         self.Pn: Dict[str, torch.Tensor] = {}       # transposed folded weights in the fragment order of mbx_rows_lnbwd_t
+        # Round 5: the FORWARD residual GEMM (proj / fc2) of a sub-layer that is followed by a LayerNorm runs on the same row-owner shape
+        # and leaves the plain normalisation of its output rows with them (mbx_rows_resid_ln): three of the four LayerNorm launches of a
+        # Block -- each a second read of the fp32 rows -- disappear.  Folded sequencing only (the kernel writes xhat, not gamma xhat +
+        # beta), no dropout on the branch.  MBX_ROWS_RESID_LN=0: the A/B switch.
+        self.rows_resid_ln = (os.environ.get('MBX_ROWS_RESID_LN', '1') == '1' and bool(getattr(ops, 'can_rows_resid_ln', lambda *_: False)(tdtype, cfg)))
+        self.Pf: Dict[str, torch.Tensor] = {}       # proj / fc2 weights of those sub-layers in the fragment order of the row-owner kernels
         # Round 5: with the row means taken by that kernel the GELU' epilogue no longer has to produce the dot of
         # du with the pre-activation, so fc1's forward epilogue saves gelu'(u) -- taken from the fp32 accumulator -- INSTEAD of u (same
         # bytes) and the backward epilogue is one multiply (mbx_gemm_nt_gelu_d / mbx_gemm_nt_mul).  MBX_GELU_D=0: the A/B switch.
@@ -272,7 +278,7 @@ class Engine:
         version counters (as they bypass autograd's own checks): `hip_ops.get().weight_cache.clear()` after such an edit."""
         if need_grad or not hasattr(self.ops, 'weight_cache') or self.dev.type != 'cuda' or torch.cuda.is_current_stream_capturing():
             return None
-        return (tuple((p.data_ptr(), p._version) for p in self.P.values()), self.T, self.fold, self.rawln, self.proj_mlp, self.x3)
+        return (tuple((p.data_ptr(), p._version) for p in self.P.values()), self.T, self.fold, self.rawln, self.proj_mlp, self.x3, self.rows_resid_ln)
 
     def prepare_weights(self, need_grad: bool):
         """T-typed copies of every Linear weight (and their transposes when a backward follows); with LayerNorm folding the
@@ -286,12 +292,12 @@ class Engine:
             # same storage + same versions is not enough: a NEW model built after the old one died gets the same addresses and the
             # same (small) version numbers from the allocator -- the entry must be about these very tensor objects
             if hit is not None and hit[0] == key and len(hit[1]) == len(P) and all(r() is p for r, p in zip(hit[1], P.values())):
-                self.Wn, self.Wt, self.Bf, self.Rs, self.Pk, self.Pk_proj = hit[2]
+                self.Wn, self.Wt, self.Bf, self.Rs, self.Pk, self.Pk_proj, self.Pf = hit[2]
                 return
         self._prepare_weights(need_grad)
         if key is not None:
             import weakref
-            ops.weight_cache[self.dev.index] = (key, [weakref.ref(p) for p in P.values()], (self.Wn, self.Wt, self.Bf, self.Rs, self.Pk, self.Pk_proj))
+            ops.weight_cache[self.dev.index] = (key, [weakref.ref(p) for p in P.values()], (self.Wn, self.Wt, self.Bf, self.Rs, self.Pk, self.Pk_proj, self.Pf))
 
     def _prepare_weights(self, need_grad: bool):
         cfg, ops, P = self.cfg, self.ops, self.P
@@ -302,6 +308,14 @@ class Engine:
             fn, ft, self.Bf, self.Rs = ops.fold_norm_weights(P, pairs, need_grad, self.T)
             self.Wn.update(fn)
             self.Wt.update(ft)
+            if self.rows_resid_ln and not self.rawln:
+                # proj / fc2 of the first three sub-layers of every Block (the fourth feeds the fusion, not a LayerNorm)
+                self.Pf = {}
+                for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')):
+                    for i in range(cfg.depth):
+                        for typ, _norm, m, _mode in ORDER[kind][:-1]:
+                            lin = f'{stream}.{i}.{m}.' + ('proj' if typ == 'attn' else 'fc2')
+                            self.Pf[lin] = ops.rows_n_pack(self.Wn[lin])
             if need_grad and self.rows_lnbwd and self.gstream_allowed:
                 # (not for the first sub-layer of a Block: its LayerNorm backward leaves the Block in fp32 and adds the other stream's
                 # gradient -- the tile kernel's epilogue)
@@ -447,10 +461,14 @@ class Engine:
         return x, svs
 
     def _resid_gemm(self, a, lin, x, dm, pre, nxt):
-        """y = x + a . W^T + b (fp32 residual stream): returns (y, None) -- the second value is the `ln` slot of the next sub-layer,
-        which no residual GEMM fills since round 5 (the opt-in kernel that also normalised its row block is gone)."""
+        """y = x + a . W^T + b (fp32 residual stream): returns (y, ln) -- ln = (xhat, mean, rstd) of y for the next sub-layer when the
+        row-owner kernel ran (it owns whole rows, so LayerNorm's statistics cost it nothing), else None."""
         cfg, ops, P = self.cfg, self.ops, self.P
         y = self._f(self.M, cfg.C)
+        if self.fold and nxt is not None and lin in self.Pf and not (dm is not None and (dm[0] > 0 or dm[3] > 0)):
+            xn, mean, rstd = self._op(self.M, cfg.C), self._f(self.M), self._f(self.M)
+            ops.rows_resid_ln(a, self.Pf[lin], P[lin + '.bias'], x, y, xn, mean, rstd, cfg.eps)
+            return y, (xn, mean, rstd)
         ops.gemm_nt(a, self.Wn[lin], P[lin + '.bias'], EPI_RESID, resid=x, out_f=y)
         if (not self.rawln) and dm is not None and (dm[0] > 0 or dm[3] > 0):      # proj_drop / MLP drop + DropPath on the branch (DSTformer.py:84,148-149,241-242)
             ops.residual_drop(y, x, cfg.J, dm[0], dm[1], dm[3], dm[4])

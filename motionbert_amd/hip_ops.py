@@ -94,6 +94,7 @@ SIGNATURES = {
     'mbx_rows_n_pack_bytes': (_sz, [_i]),
     'mbx_rows_n_pack': (_i, [_vp, _vp, _i, _vp]),
     'mbx_rows_lnbwd_t': (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
+    'mbx_rows_resid_ln': (_i, [_vp] * 8 + [_f, _i, _i, _i, _vp]),
     'mbx_mfma_probe_ws': (_sz, [_i]),
     'mbx_mfma_probe': (_i, [_vp, _i, _i, C.c_uint, _vp, _vp]),
     'mbx_adamw_step': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _i, _vp]),
@@ -364,6 +365,14 @@ class HipOps:
         """dx_t = T(dres_t + LayerNorm'(dy . w^T)) with both row means taken in the kernel (no row dots from the producers of dy)."""
         M, K = dy_t.shape
         self._ck(self.lib.mbx_rows_lnbwd_t(_p(dy_t), _p(packed), _p(xhat), _p(rstd), _p(dres_t), _p(dx_t), M, dx_t.shape[1], K, self._stream()))
+
+    can_rows_resid_ln = can_rows_lnbwd      # same shape constraints (dim_feat 512; contraction lengths C and hidden)
+
+    def rows_resid_ln(self, a_t, packed, bias, resid, y, xhat, mean, rstd, eps):
+        """y = resid + a . w^T + bias (fp32) and the plain LayerNorm of its rows (xhat in the operand type, mean, rstd) in one kernel."""
+        M, K = a_t.shape
+        self._ck(self.lib.mbx_rows_resid_ln(_p(a_t), _p(packed), _p(bias), _p(resid), _p(y), _p(xhat), _p(mean), _p(rstd), float(eps), M, y.shape[1], K,
+                                            self._stream()))
 
     # ------------------------------------------------------------------ measurement aid (bench.py, tools/clock_power.py)
     def mfma_probe(self, seconds: float = 0.25, wgs_per_cu: int = 1, device=None):

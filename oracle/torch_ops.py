@@ -151,6 +151,21 @@ class MockOps:
         c2 = (acc * xh).mean(-1, keepdim=True)
         dx_t.copy_((dres_t.float() + rstd[:, None] * (acc - c1 - xh * c2)).to(dx_t.dtype))
 
+    fuse_rows_resid_ln = True     # tests switch it off to exercise the residual GEMM + stand-alone LayerNorm sequencing
+
+    def can_rows_resid_ln(self, tdtype, cfg):
+        return bool(self.fuse_rows_resid_ln)
+
+    def rows_resid_ln(self, a_t, packed, bias, resid, y, xhat, mean, rstd, eps):
+        """mbx_rows_resid_ln: y = resid + a . w^T + bias (fp32); xhat = T((y - mean) rstd), two-pass statistics of the fp32 rows of y."""
+        self._log('rows_resid_ln')
+        y.copy_(resid + a_t.float() @ packed.float().t() + bias)
+        mu = y.mean(-1)
+        rs = torch.rsqrt(((y - mu[:, None]) ** 2).mean(-1) + eps)
+        mean.copy_(mu)
+        rstd.copy_(rs)
+        xhat.copy_(((y - mu[:, None]) * rs[:, None]).to(xhat.dtype))
+
     def unfold_norm_grads(self, dw, db, w, gamma, beta, dgamma, dbeta):
         """in place: dw <- gamma[k] dw + db[n] beta[k];  dgamma = sum_n w dw';  dbeta = sum_n w db."""
         self._log('unfold_norm_grads')

@@ -9,6 +9,7 @@ checked through a LayerNorm'd input with known constants."""
 import pytest
 import torch
 
+from motionbert_amd.engine import EPI_RESID
 from tests.mock_ops import MockOps
 from tests.test_gpu_kernels import DEV, check, rnd
 
@@ -148,6 +149,42 @@ def test_rows_lnbwd_t(ops, M, K):
         xh.backward(dy.float() @ w.float().t())
         check(f'rows_lnbwd_t.vs_autograd.{M}x{K}', out.float() - dres.float(), xg.grad, 2e-2)
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize('M,K', [(128, 512), (4131, 512), (4131, 1024), (70227, 512), (33, 1024), (2 * 243 * 17, 512), (129, 1536), (264384, 1024), (300, 768)])
+def test_rows_resid_ln(ops, M, K):
+    """mbx_rows_resid_ln (csrc/gemm_rows_n.hip): y = resid + a . w^T + bias in fp32 and the plain LayerNorm of its rows (xhat, mean, rstd)
+    from the same registers, against the torch restatement and against what the product ran before -- the residual epilogue of
+    mbx_gemm_nt followed by mbx_layernorm_fwd; rows with a large common offset included (the statistics are two-pass)."""
+    N = 512
+    a = rnd(M, K, seed=M + 1, dtype=BF, scale=0.7)
+    w = rnd(N, K, seed=M + 2, dtype=BF, scale=0.05)
+    bias = rnd(N, seed=M + 3, scale=0.3)
+    resid = rnd(M, N, seed=M + 4) * (0.5 + rnd(M, 1, seed=M + 5).abs()) + 3.0 * rnd(M, 1, seed=M + 6)
+    mk = lambda: [torch.full((M, N), float('nan'), device=DEV), torch.full((M, N), float('nan'), device=DEV, dtype=BF),
+                  torch.full((M,), float('nan'), device=DEV), torch.full((M,), float('nan'), device=DEV)]
+    g, r, o = mk(), mk(), mk()
+    ops.rows_resid_ln(a, ops.rows_n_pack(w), bias, resid, *g, 1e-6)
+    MockOps().rows_resid_ln(a, w, bias, resid, *r, 1e-6)
+    tag = f'{M}x{K}'
+    for name, u, v, tol in zip(('y', 'xhat', 'mean', 'rstd'), g, r, (2e-6, 4e-3, 1e-5, 1e-5)):
+        assert torch.isfinite(u.float()).all(), name
+        check(f'rows_resid_ln.{name}.{tag}', u, v, tol)
+    ops.gemm_nt(a, w, bias, EPI_RESID, resid=resid, out_f=o[0])
+    ops.layernorm_fwd(o[0], None, None, 1e-6, o[1], o[2], o[3])
+    check(f'rows_resid_ln.y_vs_tile_kernel.{tag}', g[0], o[0], 2e-6)
+    check(f'rows_resid_ln.xhat_vs_layernorm_fwd.{tag}', g[1], o[1], 4e-3)
+    check(f'rows_resid_ln.rstd_vs_layernorm_fwd.{tag}', g[3], o[3], 1e-5)
+
+
+def test_rows_resid_ln_rejects_bad_shapes(ops):
+    a, w = rnd(64, 512, seed=1, dtype=BF), rnd(512, 512, seed=2, dtype=BF)
+    pk = ops.rows_n_pack(w)
+    f = lambda *s: torch.empty(*s, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.rows_resid_ln(a, pk, f(256), f(64, 256), f(64, 256), torch.empty(64, 256, device=DEV, dtype=BF), f(64), f(64), 1e-6)      # N != 512
+    with pytest.raises(RuntimeError):
+        ops.rows_resid_ln(rnd(64, 384, seed=3, dtype=BF), pk, f(512), f(64, 512), f(64, 512), torch.empty(64, 512, device=DEV, dtype=BF), f(64), f(64), 1e-6)   # K % 256
 
 
 def test_rows_lnbwd_t_rejects_bad_shapes(ops):

@@ -35,7 +35,7 @@ def test_engine_fp32_matches_reference_gradients(name, fold, rows):
     _load(model, z)
     model.precision, model.fold_ln = 'fp32', fold
     ops = MockOps()
-    ops.fuse_rows_lnbwd = rows
+    ops.fuse_rows_lnbwd = ops.fuse_rows_resid_ln = rows
     x = torch.from_numpy(z['x']).requires_grad_(True)
     out = M.run(ops, model, x)
     assert out.shape == z['out'].shape and out.dtype == torch.float32
@@ -63,9 +63,14 @@ def test_engine_fp32_matches_reference_gradients(name, fold, rows):
     assert ops.calls.count('lnbwd_rowc') == ((2 * depth if rw else 8 * depth) if fold else 0)
     # gradient stream in the operand type: the three inner LayerNorm-backward GEMMs of every Block write no fp32 dx
     assert ops.calls.count('gemm_nt.lnbwd.stream') + ops.calls.count('rows_lnbwd_t') == (6 * depth if fold else 0)
-    assert ops.calls.count('rows_lnbwd_t') == ops.calls.count('rows_n_pack') == (6 * depth if rw else 0)
-    # forward: 8 residual GEMMs per level
-    assert ops.calls.count('gemm_nt.2') == 8 * depth
+    assert ops.calls.count('rows_lnbwd_t') == (6 * depth if rw else 0)
+    # forward: 8 residual GEMMs per level; with the row-owner kernel the six that are followed by a LayerNorm inside their Block bring
+    # its output along (three of the four LayerNorm launches of a Block go)
+    assert ops.calls.count('rows_resid_ln') == (6 * depth if rw else 0)
+    assert ops.calls.count('gemm_nt.2') + ops.calls.count('rows_resid_ln') == 8 * depth
+    assert ops.calls.count('rows_n_pack') == (12 * depth if rw else 0)
+    # stand-alone LayerNorm forwards: 8 per level, minus the two per later level that the fusion kernel of the level before provides
+    assert ops.calls.count('layernorm_fwd') == 8 * depth - 2 * (depth - 1) - (6 * depth if rw else 0)
     # the MLPs of a Block (4 per level) save gelu'(u) instead of u where the row-owner tail follows: one-multiply backward epilogue
     assert ops.calls.count('gemm_nt.gelu_d') == ops.calls.count('gemm_nt.mul') == (4 * depth if rw else 0)
     assert ops.calls.count('gemm_nt.1') == (0 if rw else 4 * depth)      # EPI_GELU
