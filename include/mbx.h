@@ -339,19 +339,22 @@ int mbx_flip_average(const float* out2, const int* perm, float* out, int B, int 
 /* ---- "N-resident" row-owner GEMM with the LayerNorm backward as its epilogue (bf16; csrc/gemm_rows_n.hip; round 5) ---------------------
  * The input gradient of a folded (LayerNorm -> Linear) pair INSIDE a Block (DSTformer.py:241-249: norm1 -> attn.qkv :143, norm2 ->
  * mlp.fc1 :80; backward by autograd in the reference) in one launch, without row dots from the producers of dY:
- *     dxhat = dy . w^T   (dy bf16 [M,K], w bf16 [512,K] = mbx_fold_norm_weights' transposed folded weight, packed by mbx_rows_n_pack)
+ *     dxhat = dy . w^T   (dy bf16 [M,K], w bf16 [512,K] = mbx_fold_norm_weights' transposed folded weight, packed by mbx_rows_n_pack_many)
  *     dx_t  = bf16( dres_t + rstd (dxhat - mean_k dxhat - xhat mean_k(dxhat xhat)) )          all [M,512]
  * A workgroup owns 128 complete rows (256 accumulator registers per wave), so both row means come from the accumulators; xhat bf16
  * [M,512] and rstd f32 [M] are what mbx_layernorm_fwd (gamma = NULL) left, dres_t / dx_t the gradient of the residual stream in the
  * operand type (as mbx_gemm_nt_lnbwd_t with dx = NULL).  N must be 512; K % 256 == 0.  dx_t must not alias an input. */
 size_t mbx_rows_n_pack_bytes(int K);
-int mbx_rows_n_pack(const void* w, void* packed, int K, void* stream);
+/* packs n_desc operands in ONE launch (a training step re-packs 60 weights): record r of desc = {w bf16 [512,K_r], packed_r
+ * (mbx_rows_n_pack_bytes(K_r) bytes), K_r} (3 x int64, device memory); max_k = the largest K_r; every K_r >= 512 and % 256 == 0 (the
+ * caller's responsibility: the records live on the device). */
+int mbx_rows_n_pack_many(const int64_t* desc, int n_desc, int max_k, void* stream);
 int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* xhat, const float* rstd, const void* dres_t, void* dx_t, int M,
                      int N, int K, void* stream);
 /* The FORWARD residual GEMM of a sub-layer that is followed by a LayerNorm, on the same row-owner shape (proj / fc2 + residual,
  * DSTformer.py:241-249, and the next norm1 / norm2): y = resid + a . w^T + bias (fp32 [M,512]); xhat = (y - mean(y)) rstd(y) (bf16 [M,512],
  * the plain normalisation: gamma and beta live in the folded weights of the Linear the LayerNorm feeds), mean / rstd fp32 [M] (two-pass
- * statistics of the fp32 rows, eps inside the square root).  packed = mbx_rows_n_pack of w [512,K].  bf16; N == 512, K >= 512,
+ * statistics of the fp32 rows, eps inside the square root).  packed = mbx_rows_n_pack_many's image of w [512,K].  bf16; N == 512, K >= 512,
  * K % 256 == 0, M * 2048 < 2^32. */
 int mbx_rows_resid_ln(const void* a, const void* packed, const float* bias, const float* resid, float* y, void* xhat, float* mean,
                       float* rstd, float eps, int M, int N, int K, void* stream);

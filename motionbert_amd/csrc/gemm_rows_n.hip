@@ -31,7 +31,12 @@ static constexpr int RN_RING = 4 * RN_STAGE;
 
 // packed stream: fragment (kk, nt) at index kk * 16 + nt; lane (i, g) owns bytes [16 l, 16 l + 16) = w[32 nt + i][16 kk + 8 g + t],
 // t = 0..7, w = the [512, K] row-major operand of mbx_gemm_nt (for dX: the transposed folded weight W'^T)
-__global__ __launch_bounds__(256) void rows_n_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int K) {
+// One launch packs many operands: record r of `desc` = {src bf16 [512, K], dst, K} (3 x int64); blockIdx.y = record
+__global__ __launch_bounds__(256) void rows_n_pack_many_kernel(const int64_t* __restrict__ desc) {
+    const int64_t* d = desc + (size_t)blockIdx.y * 3;
+    const bf16_t* w = reinterpret_cast<const bf16_t*>(d[0]);
+    bf16_t* out = reinterpret_cast<bf16_t*>(d[1]);
+    const int K = (int)d[2];
     const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (frag >= (K / 16) * 16) return;
     const int kk = frag >> 4, nt = frag & 15, i = lane & 31, g = lane >> 5;
@@ -403,12 +408,11 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
 // ---- C ABI -------------------------------------------------------------------------------------------------------------------
 extern "C" size_t mbx_rows_n_pack_bytes(int K) { return (size_t)RN_N * K * sizeof(bf16_t); }
 
-extern "C" int mbx_rows_n_pack(const void* w, void* packed, int K, void* stream) {
-    MBX_CHECK_ARG(w && packed, "rows_n_pack: null pointer");
-    MBX_CHECK_ARG(K >= 512 && K % 256 == 0, "rows_n_pack: K=%d (%% 256, >= 512)", K);
-    const int nfrag = (K / 16) * 16;
-    hipLaunchKernelGGL(rows_n_pack_kernel, dim3((nfrag + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)packed, K);
-    MBX_LAUNCH_CHECK("rows_n_pack");
+extern "C" int mbx_rows_n_pack_many(const int64_t* desc, int n_desc, int max_k, void* stream) {
+    MBX_CHECK_ARG(desc && n_desc > 0, "rows_n_pack_many: bad arguments");
+    MBX_CHECK_ARG(max_k >= 512 && max_k % 256 == 0, "rows_n_pack_many: max_k=%d (%% 256, >= 512)", max_k);
+    hipLaunchKernelGGL(rows_n_pack_many_kernel, dim3(((max_k / 16) * 16 + 3) / 4, n_desc), dim3(256), 0, (hipStream_t)stream, desc);
+    MBX_LAUNCH_CHECK("rows_n_pack_many");
     return 0;
 }
 

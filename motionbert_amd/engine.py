@@ -310,17 +310,15 @@ class Engine:
             self.Wt.update(ft)
             if self.rows_resid_ln and not self.rawln:
                 # proj / fc2 of the first three sub-layers of every Block (the fourth feeds the fusion, not a LayerNorm)
-                self.Pf = {}
-                for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')):
-                    for i in range(cfg.depth):
-                        for typ, _norm, m, _mode in ORDER[kind][:-1]:
-                            lin = f'{stream}.{i}.{m}.' + ('proj' if typ == 'attn' else 'fc2')
-                            self.Pf[lin] = ops.rows_n_pack(self.Wn[lin])
+                lins = [f'{stream}.{i}.{m}.' + ('proj' if typ == 'attn' else 'fc2') for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts'))
+                        for i in range(cfg.depth) for typ, _norm, m, _mode in ORDER[kind][:-1]]
+                self.Pf = dict(zip(lins, ops.rows_n_pack_many([self.Wn[lin] for lin in lins])))
             if need_grad and self.rows_lnbwd and self.gstream_allowed:
                 # (not for the first sub-layer of a Block: its LayerNorm backward leaves the Block in fp32 and adds the other stream's
                 # gradient -- the tile kernel's epilogue)
                 first = {f'{stream}.{i}.{ORDER[kind][0][2]}.qkv' for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')) for i in range(cfg.depth)}
-                self.Pn = {lin: ops.rows_n_pack(ft[lin]) for lin, _ in pairs if lin not in first}
+                lins = [lin for lin, _ in pairs if lin not in first]
+                self.Pn = dict(zip(lins, ops.rows_n_pack_many([ft[lin] for lin in lins])))
             if self.rawln:
                 for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')):
                     for i in range(cfg.depth):

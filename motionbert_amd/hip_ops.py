@@ -92,8 +92,8 @@ SIGNATURES = {
     'mbx_embed_fwd_tta': (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     'mbx_flip_average': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mbx_rows_n_pack_bytes': (_sz, [_i]),
-    'mbx_rows_n_pack': (_i, [_vp, _vp, _i, _vp]),
     'mbx_rows_lnbwd_t': (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
+    'mbx_rows_n_pack_many': (_i, [_i64p, _i, _i, _vp]),
     'mbx_rows_resid_ln': (_i, [_vp] * 8 + [_f, _i, _i, _i, _vp]),
     'mbx_mfma_probe_ws': (_sz, [_i]),
     'mbx_mfma_probe': (_i, [_vp, _i, _i, C.c_uint, _vp, _vp]),
@@ -353,13 +353,39 @@ class HipOps:
         return tdtype == torch.bfloat16 and cfg.C == 512 and cfg.hidden % 256 == 0
 
     def rows_n_pack(self, w_t):
-        """w bf16 [512, K] (the operand of the dX GEMM) in the fragment order of mbx_rows_lnbwd_t."""
-        N, K = w_t.shape
-        if N != 512:
-            raise RuntimeError(f'rows_n_pack: {N} output columns (512)')
-        packed = torch.empty(int(self.lib.mbx_rows_n_pack_bytes(K)), dtype=torch.uint8, device=w_t.device)
-        self._ck(self.lib.mbx_rows_n_pack(_p(w_t), _p(packed), K, self._stream()))
-        return packed
+        """w bf16 [512, K] (the operand of the dX GEMM) in the fragment order of mbx_rows_lnbwd_t / mbx_rows_resid_ln."""
+        return self.rows_n_pack_many([w_t])[0]
+
+    def rows_n_pack_many(self, ws):
+        """rows_n_pack of every operand of the list in one launch; the results are views into one buffer.  The descriptor table lives on the
+        device and is cached by the operands' offsets from the first one: no host-to-device copy in the steady state (nor inside a graph
+        capture after a warm-up step); source and destination addresses are filled in on the device."""
+        if not ws:
+            return []
+        dev = ws[0].device
+        for w in ws:
+            if w.shape[0] != 512 or w.shape[1] < 512 or w.shape[1] % 256 or w.dtype != torch.bfloat16 or not w.is_contiguous():
+                raise RuntimeError(f'rows_n_pack_many: operand {tuple(w.shape)} {w.dtype} (bf16 [512, K], K % 256 == 0, K >= 512, contiguous)')
+        base = ws[0].data_ptr()       # (the operands of one call are views into one flat buffer: their relative offsets are what is stable)
+        key = ('rnpack', tuple((w.data_ptr() - base, w.shape[1]) for w in ws), dev.index)
+        with self._lock:
+            ent = self._desc_cache.get(key)
+            if ent is None:
+                offs, off = [], 0
+                for w in ws:
+                    offs.append(off)
+                    off += 512 * w.shape[1] * 2
+                if len(self._desc_cache) > 64:
+                    self._desc_cache.clear()
+                ent = dict(desc=torch.tensor([[w.data_ptr() - base, o, w.shape[1]] for w, o in zip(ws, offs)], dtype=torch.int64).to(dev), offs=offs, total=off,
+                           max_k=max(w.shape[1] for w in ws))
+                self._desc_cache[key] = ent
+        flat = torch.empty(ent['total'], dtype=torch.uint8, device=dev)
+        desc = ent['desc'].clone()
+        desc[:, 0] += base
+        desc[:, 1] += flat.data_ptr()
+        self._ck(self.lib.mbx_rows_n_pack_many(desc.data_ptr(), len(ws), ent['max_k'], self._stream()))
+        return [flat[o:o + 512 * w.shape[1] * 2] for w, o in zip(ws, ent['offs'])]
 
     def rows_lnbwd_t(self, dy_t, packed, xhat, rstd, dres_t, dx_t):
         """dx_t = T(dres_t + LayerNorm'(dy . w^T)) with both row means taken in the kernel (no row dots from the producers of dy)."""

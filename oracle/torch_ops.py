@@ -142,6 +142,10 @@ class MockOps:
         self._log('rows_n_pack')
         return w_t
 
+    def rows_n_pack_many(self, ws):
+        self._log('rows_n_pack_many')
+        return list(ws)
+
     def rows_lnbwd_t(self, dy_t, packed, xhat, rstd, dres_t, dx_t):
         """mbx_rows_lnbwd_t: dx_t = T(dres_t + rstd (dxhat - mean dxhat - xhat mean(dxhat xhat))), dxhat = dy . w^T in fp32."""
         self._log('rows_lnbwd_t')

@@ -187,6 +187,28 @@ def test_rows_resid_ln_rejects_bad_shapes(ops):
         ops.rows_resid_ln(rnd(64, 384, seed=3, dtype=BF), pk, f(512), f(64, 512), f(64, 512), torch.empty(64, 512, device=DEV, dtype=BF), f(64), f(64), 1e-6)   # K % 256
 
 
+def test_rows_n_pack_many(ops):
+    """One launch packs operands of different contraction lengths; every image equals the one a launch of its own makes, the fragment
+    layout is the documented one (fragment (kk, nt), lane (i, g): w[32 nt + i][16 kk + 8 g .. + 7]), and a second call with the same
+    layout of sources (the steady state of training) reuses the cached descriptor table."""
+    flat = rnd(512 * (512 + 1536 + 1024), seed=7, dtype=BF)
+    ws, off = [], 0
+    for K in (512, 1536, 1024):
+        ws.append(flat[off:off + 512 * K].view(512, K))
+        off += 512 * K
+    many = ops.rows_n_pack_many(ws)
+    for w, pk in zip(ws, many):
+        K = w.shape[1]
+        assert pk.numel() == 512 * K * 2
+        assert torch.equal(pk, ops.rows_n_pack(w.clone()))
+        img = pk.view(torch.bfloat16).view(K // 16, 16, 2, 32, 8)              # [kk][nt][g][i][t]
+        ref = w.view(16, 32, K // 16, 2, 8).permute(2, 0, 3, 1, 4)             # w[32 nt + i][16 kk + 8 g + t]
+        assert torch.equal(img, ref)
+    n_cached = len(ops._desc_cache)
+    again = ops.rows_n_pack_many([w for w in ws])
+    assert len(ops._desc_cache) == n_cached and all(torch.equal(x, y) for x, y in zip(many, again))
+
+
 def test_rows_lnbwd_t_rejects_bad_shapes(ops):
     dy, w = rnd(64, 384, seed=1, dtype=BF), rnd(512, 384, seed=2, dtype=BF)
     with pytest.raises(RuntimeError):

@@ -68,7 +68,7 @@ def test_engine_fp32_matches_reference_gradients(name, fold, rows):
     # its output along (three of the four LayerNorm launches of a Block go)
     assert ops.calls.count('rows_resid_ln') == (6 * depth if rw else 0)
     assert ops.calls.count('gemm_nt.2') + ops.calls.count('rows_resid_ln') == 8 * depth
-    assert ops.calls.count('rows_n_pack') == (12 * depth if rw else 0)
+    assert ops.calls.count('rows_n_pack_many') == (2 if rw else 0)      # one launch for the forward set, one for the backward set
     # stand-alone LayerNorm forwards: 8 per level, minus the two per later level that the fusion kernel of the level before provides
     assert ops.calls.count('layernorm_fwd') == 8 * depth - 2 * (depth - 1) - (6 * depth if rw else 0)
     # the MLPs of a Block (4 per level) save gelu'(u) instead of u where the row-owner tail follows: one-multiply backward epilogue
