@@ -463,7 +463,8 @@ class Engine:
         row-owner kernel ran (it owns whole rows, so LayerNorm's statistics cost it nothing), else None."""
         cfg, ops, P = self.cfg, self.ops, self.P
         y = self._f(self.M, cfg.C)
-        if self.fold and nxt is not None and lin in self.Pf and not (dm is not None and (dm[0] > 0 or dm[3] > 0)):
+        # (the kernel addresses its 2-KiB rows with 32-bit offsets: beyond 2^21 rows the tile kernel + LayerNorm take over)
+        if self.fold and nxt is not None and lin in self.Pf and self.M < (1 << 21) and not (dm is not None and (dm[0] > 0 or dm[3] > 0)):
             xn, mean, rstd = self._op(self.M, cfg.C), self._f(self.M), self._f(self.M)
             ops.rows_resid_ln(a, self.Pf[lin], P[lin + '.bias'], x, y, xn, mean, rstd, cfg.eps)
             return y, (xn, mean, rstd)
@@ -540,7 +541,7 @@ class Engine:
         # the derivative instead of the pre-activation where backward will run the row-owner tail (every MLP of a Block does: never the
         # first sub-layer, so bf16 gradient in and out and no second summand)
         save_d = bool(need_grad and self.fold and self.gelu_d and self.gstream_allowed and not self.recompute and not mlp_drop
-                      and f'{pre}.{mlp}.fc1' in self.Pn)
+                      and f'{pre}.{mlp}.fc1' in self.Pn and self.M < (1 << 22))
         if save_d:
             ops.gemm_nt_gelu_d(xn, self.Wn[f'{pre}.{mlp}.fc1'], self.Bf[f'{pre}.{mlp}.fc1'], u, g)
         else:
@@ -697,7 +698,7 @@ class Engine:
 
     def _rows_tail_ok(self, lin, dy_t, extra, need_t) -> bool:
         """The row-owner LayerNorm-backward GEMM serves a folded pair whose gradient arrives and leaves in the operand type only."""
-        return bool(self.rows_lnbwd and self.gstream and need_t and dy_t is not None and extra is None and lin in self.Pn)
+        return bool(self.rows_lnbwd and self.gstream and need_t and dy_t is not None and extra is None and lin in self.Pn and self.M < (1 << 22))
 
     def _fold_tail(self, dY, part, sv, lin, norm, dy, dy_t, extra, need_t):
         """Folded (LayerNorm -> Linear) pair, backward from the Linear's output gradient dY and its row dots `part`: weight
