@@ -108,6 +108,8 @@ class TimedOps:
                 flops = 2.0 * first(a[0]).shape[0] * first(a[0]).shape[1] * first(a[1]).shape[1]
             elif name == 'rows_lnbwd_t':        # (dy [M, K], packed W'^T, xhat [M, 512], ...): the row-owner dX GEMM of a folded pair
                 flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[2].shape[1]
+            elif name == 'rows_resid_ln':       # (a [M, K], packed W, bias, resid [M, 512], ...): the row-owner residual GEMM + LayerNorm
+                flops = 2.0 * a[0].shape[0] * a[0].shape[1] * a[3].shape[1]
             self.rec.append((name, flops, e0, e1))
             return r
         return wrapped
@@ -808,7 +810,7 @@ def main():
             roof['sustained_error'] = f'{type(e).__name__}: {e}'[:200]
         roof['by_entry'] = {k: dict(launches=agg[k]['calls'], ms=round(agg[k]['ms'], 3), tflops=round(agg[k]['flops'] / (agg[k]['ms'] * 1e-3) / 1e12, 1),
                                     frac=round(agg[k]['flops'] / (agg[k]['ms'] * 1e-3) / 1e12 / peak, 4))
-                            for k in NT_FAMILY + ('gemm_tn', 'rows_lnbwd_t') if k in agg and agg[k]['ms'] > 0}
+                            for k in NT_FAMILY + ('gemm_tn', 'rows_lnbwd_t', 'rows_resid_ln') if k in agg and agg[k]['ms'] > 0}
     flops_step = wl_flops if wl_flops is not None else 3.0 * model_flops_fwd(FULL, T) * B
     out = {
         'metric': 'clips/sec [B,243,17,3] DSTformer fwd+bwd', 'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world,
