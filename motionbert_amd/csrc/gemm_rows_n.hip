@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
 // quarter of resid each (fp32, by LDS-DMA, double-buffered: a row takes 512 bytes, its 16-byte piece p sits at slot p ^ row); y is
 // written over the resid it was made from, read back row-major and stored as 512-byte row segments while the accumulators keep y;
 // then mean and rstd, then xhat through the fifth 8-KiB buffer exactly as dx leaves the LayerNorm-backward kernel above.
+// (Measured and dropped: the first two quarters of resid requested into registers during the last trip of the loop, as the xhat
+// prefetch of the kernel above -- 0.380 -> 0.381 ms at K = 512, 0.465 -> 0.490 at K = 1024: across the CUs this kernel is bound by
+// HBM bandwidth (mixed reads and writes at ~4.2 TB/s of algorithmic bytes), not by the latency of one tile's loads.)
 __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* __restrict__ a, const char* __restrict__ wpk,
                                                                 const float* __restrict__ bias, const float* __restrict__ resid,
                                                                 float* __restrict__ y, bf16_t* __restrict__ xhat_o,

@@ -67,3 +67,53 @@ def test_device_code_policy(lib, tmp_path):
         assert 'ds_bpermute' not in asm and 'ds_permute' not in asm and 'ds_swizzle' not in asm, f'{o.name}: LDS-crossbar permute found'
         n_mfma += asm.count('v_mfma_f32_32x32x16_bf16')
     assert n_mfma > 100, 'expected the bf16 MFMA kernels in the device code'
+
+
+def test_asm_prefetch_registers_are_left_alone(lib, tmp_path):
+    """The N-resident LayerNorm-backward kernel (csrc/gemm_rows_n.hip) requests part of its epilogue's input with inline-asm loads inside
+    the last trip of the loop.  To the compiler an asm output is valid where the statement stands: if register pressure made it copy
+    or reuse one of those registers before the kernel's own `s_waitcnt vmcnt(0)`, the copy would hold stale bits (round 5 found both
+    failure modes in the epilogue of an earlier version).  Checked on the disassembly: its 32 loads have 128 distinct
+    destination registers, and no instruction between a load and that wait names a register it has already written."""
+    import re
+    import shutil
+    import subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not available')
+    from motionbert_amd import hip_ops
+    copy = tmp_path / 'libmbx.so'
+    shutil.copy(hip_ops.LIB_PATH, copy)
+    subprocess.run([objdump, '--offloading', str(copy)], check=True, capture_output=True, cwd=tmp_path)
+    seen = 0
+    for o in [p for p in tmp_path.iterdir() if 'amdgcn' in p.name]:
+        asm = subprocess.run([objdump, '-d', '--mcpu=gfx950', str(o)], check=True, capture_output=True, text=True).stdout
+        for kern in ('rows_n_lnbwd_kernel',):
+            m = re.search(r'^[0-9a-f]+ <_Z\d+' + kern + r'[^>]*>:\n(.*?)s_endpgm', asm, re.S | re.M)
+            if not m:
+                continue
+            seen += 1
+            lines = m.group(1).split('\n')
+            loads = []      # (line, first, last) of global_load_dwordx4 vdst, voff, s[..]  (the SGPR-base form only these prefetches use)
+            for n, l in enumerate(lines):
+                mm = re.search(r'global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\]', l)
+                if mm:
+                    loads.append((n, int(mm.group(1)), int(mm.group(2))))
+            assert len(loads) == 32, (kern, len(loads))
+            regs = [r for _, a, b in loads for r in range(a, b + 1)]
+            assert len(set(regs)) == 128, f'{kern}: prefetch loads share destination registers'
+            wait = next(n for n, l in enumerate(lines) if n > loads[-1][0] and 's_waitcnt vmcnt(0)' in l)
+            written = set()
+            nxt = 0
+            for n in range(loads[0][0], wait):
+                if nxt < len(loads) and loads[nxt][0] == n:
+                    written.update(range(loads[nxt][1], loads[nxt][2] + 1))
+                    nxt += 1
+                    continue
+                l = lines[n].split('//')[0]
+                used = set()
+                for mm in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', l):
+                    used.update([int(mm.group(3))] if mm.group(3) else range(int(mm.group(1)), int(mm.group(2)) + 1))
+                assert not (used & written), f'{kern}: "{l.strip()}" touches a prefetch register before the wait'
+    assert seen == 1, 'row-owner kernel not found in the device code'
+
