@@ -263,6 +263,11 @@ size_t mbx_fuse_bwd_ws(int C);
 int mbx_fuse_bwd(const float* dh, const float* x_st, const float* x_ts, const float* alpha, const float* w,
                  float* d_st, float* d_ts, void* d_st_t, void* d_ts_t, float* dw, float* db, int M, int C,
                  int dtype, void* ws, void* stream);
+/* mbx_fuse_bwd with dh = dh_a + dh_b, both bf16 [M,C]: the input gradients of the two Blocks of the level above, as their row-owner
+ * LayerNorm-backward kernels (mbx_rows_lnbwd_t) leave them (round 5: the gradient of the residual stream in the operand type across
+ * Block boundaries too).  bf16 outputs only (d_st_t, d_ts_t); ws as mbx_fuse_bwd. */
+int mbx_fuse_bwd_pair(const void* dh_a, const void* dh_b, const float* x_st, const float* x_ts, const float* alpha, const float* w,
+                      void* d_st_t, void* d_ts_t, float* dw, float* db, int M, int C, void* ws, void* stream);
 /* att_fuse=False variant (DSTformer.py:351): out = (x_st + x_ts)/2 and its backward */
 int mbx_average(const float* x_st, const float* x_ts, float* out, size_t n, void* stream);
 int mbx_average_bwd(const float* dh, float* d_st, float* d_ts, void* d_st_t, void* d_ts_t, size_t n, int dtype,

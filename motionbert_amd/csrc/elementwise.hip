@@ -1107,7 +1107,10 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ x_ts, const float* __restrict__ alpha,
                                                        const float* __restrict__ w, float* __restrict__ d_st,
                                                        float* __restrict__ d_ts, T* __restrict__ d_st_t,
-                                                       T* __restrict__ d_ts_t, float* __restrict__ part, int M, int C) {
+                                                       T* __restrict__ d_ts_t, float* __restrict__ part, int M, int C,
+                                                       const bf16_t* __restrict__ dh_a = nullptr, const bf16_t* __restrict__ dh_b = nullptr) {
+    // dh_a / dh_b (round 5): the incoming gradient as the SUM of two bf16 tensors -- the input gradients of the two Blocks of the level
+    // above, which leave their row-owner LayerNorm-backward kernels in the operand type -- instead of one fp32 tensor (same bytes)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = 4 * C + 4;
@@ -1130,7 +1133,15 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const float* __restrict__
         ROW_LOOP(k) {
             const int c = ROW_C(k);
             if (c < C) {
-                load4<float>(dh + (size_t)row * C + c, d[k]);
+                if (dh_a != nullptr) {
+                    float e[4];
+                    load4<bf16_t>(dh_a + (size_t)row * C + c, d[k]);
+                    load4<bf16_t>(dh_b + (size_t)row * C + c, e);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[k][i] += e[i];
+                } else {
+                    load4<float>(dh + (size_t)row * C + c, d[k]);
+                }
                 load4<float>(x_st + (size_t)row * C + c, a[k]);
                 load4<float>(x_ts + (size_t)row * C + c, t[k]);
 #pragma unroll
@@ -1197,6 +1208,24 @@ extern "C" int mbx_fuse_bwd(const float* dh, const float* x_st, const float* x_t
         return mbx_set_error("fuse_bwd: unknown dtype %d", dtype);
     }
     MBX_LAUNCH_CHECK("fuse_bwd");
+    if (mbx_launch_colsum(part, grid, n, 0, 4 * C, dw, s)) return 1;
+    if (mbx_launch_colsum(part, grid, n, 4 * C, 2, db, s)) return 1;
+    return 0;
+}
+
+// the same with dh = dh_a + dh_b, both bf16 [M,C] (see the kernel); bf16 outputs only
+extern "C" int mbx_fuse_bwd_pair(const void* dh_a, const void* dh_b, const float* x_st, const float* x_ts, const float* alpha, const float* w,
+                                 void* d_st_t, void* d_ts_t, float* dw, float* db, int M, int C, void* ws, void* stream) {
+    MBX_CHECK_ARG(dh_a && dh_b && x_st && x_ts && alpha && w && d_st_t && d_ts_t && dw && db && ws, "fuse_bwd_pair: null pointer");
+    MBX_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "fuse_bwd_pair: bad shape");
+    const int grid = clamp_grid((M + 3) / 4, FUSE_BWD_BLOCKS);
+    const int n = 4 * C + 4;
+    const size_t shm = (size_t)4 * n * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    DISPATCH_VPL(vpl_for(C), hipLaunchKernelGGL((fuse_bwd_kernel<bf16_t, VPL>), dim3(grid), dim3(256), shm, s, (const float*)nullptr, x_st, x_ts, alpha, w,
+                                                (float*)nullptr, (float*)nullptr, (bf16_t*)d_st_t, (bf16_t*)d_ts_t, part, M, C, (const bf16_t*)dh_a, (const bf16_t*)dh_b));
+    MBX_LAUNCH_CHECK("fuse_bwd_pair");
     if (mbx_launch_colsum(part, grid, n, 0, 4 * C, dw, s)) return 1;
     if (mbx_launch_colsum(part, grid, n, 4 * C, 2, db, s)) return 1;
     return 0;

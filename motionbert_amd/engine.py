@@ -178,6 +178,12 @@ class Engine:
         # beta), no dropout on the branch.  MBX_ROWS_RESID_LN=0: the A/B switch.
         self.rows_resid_ln = (os.environ.get('MBX_ROWS_RESID_LN', '1') == '1' and bool(getattr(ops, 'can_rows_resid_ln', lambda *_: False)(tdtype, cfg)))
         self.Pf: Dict[str, torch.Tensor] = {}       # proj / fc2 weights of those sub-layers in the fragment order of the row-owner kernels
+        # Round 5: the gradient of the residual stream stays in the operand type ACROSS Block boundaries too (levels >= 1): the first
+        # sub-layer of a Block then also takes the row-owner LayerNorm backward (no row dots, no row constants, bf16 out), and the fusion
+        # backward of the level below reads the two Blocks' input gradients as a bf16 pair and adds them (same bytes as one fp32 tensor).
+        # Numerics: four realisations on both reference-minted fixtures, every frozen gate (profiles/r05_boundary_numerics.txt).
+        # Level 0 keeps the fp32 gradient for the embedding backward.  MBX_BLOCK_GRAD_T=0: the A/B switch.
+        self.block_grad_t = os.environ.get('MBX_BLOCK_GRAD_T', '1') == '1' and self.rows_lnbwd and hasattr(ops, 'fuse_bwd_pair')
         # Round 5: with the row means taken by that kernel the GELU' epilogue no longer has to produce the dot of
         # du with the pre-activation, so fc1's forward epilogue saves gelu'(u) -- taken from the fp32 accumulator -- INSTEAD of u (same
         # bytes) and the backward epilogue is one multiply (mbx_gemm_nt_gelu_d / mbx_gemm_nt_mul).  MBX_GELU_D=0: the A/B switch.
@@ -314,9 +320,10 @@ class Engine:
                         for i in range(cfg.depth) for typ, _norm, m, _mode in ORDER[kind][:-1]]
                 self.Pf = dict(zip(lins, ops.rows_n_pack_many([self.Wn[lin] for lin in lins])))
             if need_grad and self.rows_lnbwd and self.gstream_allowed:
-                # (not for the first sub-layer of a Block: its LayerNorm backward leaves the Block in fp32 and adds the other stream's
-                # gradient -- the tile kernel's epilogue)
-                first = {f'{stream}.{i}.{ORDER[kind][0][2]}.qkv' for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')) for i in range(cfg.depth)}
+                # (not for the first sub-layer of a Block whose input gradient leaves in fp32 with the other stream's gradient added -- level 0,
+                # or every level with MBX_BLOCK_GRAD_T=0: the tile kernel's epilogue)
+                first = {f'{stream}.{i}.{ORDER[kind][0][2]}.qkv' for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')) for i in range(cfg.depth)
+                         if i == 0 or not (self.block_grad_t and cfg.att_fuse)}
                 lins = [lin for lin, _ in pairs if lin not in first]
                 self.Pn = dict(zip(lins, ops.rows_n_pack_many([ft[lin] for lin in lins])))
             if self.rawln:
@@ -593,18 +600,40 @@ class Engine:
         if on_ready is not None:
             self._join_wgrads()
             on_ready(0)
+        pair = None      # the two Blocks' input gradients of the level above, T-typed (block_grad_t), instead of their fp32 sum dh
         for i in reversed(range(cfg.depth)):
             lv = saved['levels'][i]
             # (gradient stream in the operand type: the Blocks read the T-typed copies only, the fp32 ones are not even written)
             d_st, d_ts = (None, None) if (self.gstream and cfg.att_fuse) else (self._f(M, C), self._f(M, C))
             d_st_t, d_ts_t = self._t(M, C), self._t(M, C)
             if cfg.att_fuse:
-                ops.fuse_bwd(dh, lv['x_st'], lv['x_ts'], lv['alpha'], P[f'ts_attn.{i}.weight'],
-                             d_st, d_ts, d_st_t, d_ts_t, G[f'ts_attn.{i}.weight'], G[f'ts_attn.{i}.bias'])
+                if pair is not None:
+                    ops.fuse_bwd_pair(pair[0], pair[1], lv['x_st'], lv['x_ts'], lv['alpha'], P[f'ts_attn.{i}.weight'],
+                                      d_st_t, d_ts_t, G[f'ts_attn.{i}.weight'], G[f'ts_attn.{i}.bias'])
+                else:
+                    ops.fuse_bwd(dh, lv['x_st'], lv['x_ts'], lv['alpha'], P[f'ts_attn.{i}.weight'],
+                                 d_st, d_ts, d_st_t, d_ts_t, G[f'ts_attn.{i}.weight'], G[f'ts_attn.{i}.bias'])
             else:
                 ops.average_bwd(dh, d_st, d_ts, d_st_t, d_ts_t)
+            pair = dh = None
+            # this level's Blocks hand their input gradients down T-typed when the row-owner tail can take their first sub-layer
+            out_t = bool(self.block_grad_t and self.gstream and cfg.att_fuse and i > 0 and self.M < (1 << 22)
+                         and all(f'{st}.{i}.{ORDER[kind][0][2]}.qkv' in self.Pn for st, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts'))))
             main, side = self._streams()
-            if side is not None:
+            if out_t:
+                if side is not None:
+                    side.wait_stream(main)
+                _, a_t = self._block_bwd(d_st, d_st_t, lv['st'], f'blocks_st.{i}', 'st', None, last_needs_t=True)
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        _, b_t = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', None, last_needs_t=True)
+                    main.wait_stream(side)
+                    b_t.record_stream(main)
+                else:
+                    _, b_t = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', None, last_needs_t=True)
+                pair = (a_t, b_t)
+                del a_t, b_t
+            elif side is not None:
                 # the st block runs on the main stream, the ts block on the side stream; the side stream's LAST kernel (the
                 # LayerNorm backward at the block input) waits for the main block and adds its input gradient as `extra`
                 # -- no separate d1 + d2 pass over the residual stream (1.6 GB per level)
@@ -619,11 +648,13 @@ class Engine:
                     dh, _ = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', other, last_needs_t=False)
                 main.wait_stream(side)
                 dh.record_stream(main)
+                del d1
             else:
                 d1, _ = self._block_bwd(d_st, d_st_t, lv['st'], f'blocks_st.{i}', 'st', None, last_needs_t=False)
                 # the second stream's last LN-backward also adds the first stream's input gradient
                 dh, _ = self._block_bwd(d_ts, d_ts_t, lv['ts'], f'blocks_ts.{i}', 'ts', d1, last_needs_t=False)
-            del d_st, d_st_t, d_ts, d_ts_t, d1
+                del d1
+            del d_st, d_st_t, d_ts, d_ts_t
             saved['levels'][i] = None  # release this level's activations
             if on_ready is not None:
                 self._join_wgrads()

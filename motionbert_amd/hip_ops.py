@@ -73,6 +73,7 @@ SIGNATURES = {
     'mbx_fuse_ln_fwd': (_i, [_vp] * 12 + [_f] + [_vp] * 2 + [_i] * 3 + [_vp]),
     'mbx_fuse_bwd_ws': (_sz, [_i]),
     'mbx_fuse_bwd': (_i, [_vp] * 11 + [_i, _i, _i, _vp, _vp]),
+    'mbx_fuse_bwd_pair': (_i, [_vp] * 10 + [_i, _i, _vp, _vp]),
     'mbx_average': (_i, [_vp, _vp, _vp, _sz, _vp]),
     'mbx_average_bwd': (_i, [_vp] * 5 + [_sz, _i, _vp]),
     'mbx_head_fwd': (_i, [_vp] * 4 + [_i, _i, _i, _vp]),
@@ -549,6 +550,13 @@ class HipOps:
         ws = self._ws(('fub', Cc), self.lib.mbx_fuse_bwd_ws, Cc, device=dh.device)
         self._ck(self.lib.mbx_fuse_bwd(_p(dh), _p(x_st), _p(x_ts), _p(alpha), _p(w), _p(d_st), _p(d_ts), _p(d_st_t), _p(d_ts_t),
                                        _p(dw), _p(db), M, Cc, _DT[d_st_t.dtype], _p(ws), self._stream()))
+
+    def fuse_bwd_pair(self, dh_a, dh_b, x_st, x_ts, alpha, w, d_st_t, d_ts_t, dw, db):
+        """fuse_bwd with the incoming gradient as the sum of two bf16 tensors (the two Blocks' input gradients of the level above)."""
+        M, Cc = x_st.shape
+        ws = self._ws(('fub', Cc), self.lib.mbx_fuse_bwd_ws, Cc, device=x_st.device)
+        self._ck(self.lib.mbx_fuse_bwd_pair(_p(dh_a), _p(dh_b), _p(x_st), _p(x_ts), _p(alpha), _p(w), _p(d_st_t), _p(d_ts_t), _p(dw), _p(db), M, Cc,
+                                            _p(ws), self._stream()))
 
     def average(self, x_st, x_ts, out):
         self._ck(self.lib.mbx_average(_p(x_st), _p(x_ts), _p(out), x_st.numel(), self._stream()))

@@ -504,8 +504,12 @@ class MockOps:
         del self.calls[-(3 if xn2 is not None else 2):]
         self._log('fuse_ln_fwd')
 
-    def fuse_bwd(self, dh, x_st, x_ts, alpha, w, d_st, d_ts, d_st_t, d_ts_t, dw, db):
-        self._log('fuse_bwd')
+    def fuse_bwd_pair(self, dh_a, dh_b, x_st, x_ts, alpha, w, d_st_t, d_ts_t, dw, db):
+        """mbx_fuse_bwd_pair: fuse_bwd on dh = dh_a + dh_b (two T-typed tensors), T-typed outputs only."""
+        self.fuse_bwd(dh_a.float() + dh_b.float(), x_st, x_ts, alpha, w, None, None, d_st_t, d_ts_t, dw, db, _name='fuse_bwd_pair')
+
+    def fuse_bwd(self, dh, x_st, x_ts, alpha, w, d_st, d_ts, d_st_t, d_ts_t, dw, db, _name='fuse_bwd'):
+        self._log(_name)
         C = x_st.shape[-1]
         da = torch.stack([(dh * x_st).sum(-1), (dh * x_ts).sum(-1)], -1)
         dl = alpha * (da - (da * alpha).sum(-1, keepdim=True))

@@ -99,6 +99,26 @@ def test_gemm_nt_dgelu_stats(ops, M, N, K):
     check(f'gemm_nt_dgelu_stats.part_vs_ref.{tag}', g[1], r[1], 2e-2)
 
 
+@pytest.mark.parametrize('M,C', [(4131, 512), (1000, 256), (33, 64), (16524, 512)])
+def test_fuse_bwd_pair(ops, M, C):
+    """mbx_fuse_bwd_pair: the fusion backward on dh = dh_a + dh_b (two bf16 tensors: the input gradients of the two Blocks above) is bit for
+    bit mbx_fuse_bwd on their fp32 sum, and agrees with the torch restatement."""
+    x_st, x_ts = rnd(M, C, seed=1), rnd(M, C, seed=2)
+    w, fb = rnd(2, 2 * C, seed=3, scale=0.05), rnd(2, seed=4)
+    alpha = torch.softmax(torch.cat([x_st, x_ts], -1) @ w.t() + fb, -1)
+    dh_a, dh_b = rnd(M, C, seed=5, dtype=BF), rnd(M, C, seed=6, dtype=BF, scale=0.3)
+    mk = lambda: [torch.full((M, C), 7.0, device=DEV, dtype=BF), torch.full((M, C), 7.0, device=DEV, dtype=BF), torch.empty(2, 2 * C, device=DEV),
+                  torch.empty(2, device=DEV)]
+    g, o, r = mk(), mk(), mk()
+    ops.fuse_bwd_pair(dh_a, dh_b, x_st, x_ts, alpha, w, *g)
+    ops.fuse_bwd(dh_a.float() + dh_b.float(), x_st, x_ts, alpha, w, None, None, *o)
+    MockOps().fuse_bwd_pair(dh_a, dh_b, x_st, x_ts, alpha, w, *r)
+    torch.cuda.synchronize()
+    for name, u, v, ref, tol in zip(('d_st_t', 'd_ts_t', 'dw', 'db'), g, o, r, (4e-3, 4e-3, 2e-5, 2e-5)):
+        assert torch.equal(u, v), name
+        check(f'fuse_bwd_pair.{name}.M{M}.C{C}', u, ref, tol)
+
+
 @pytest.mark.parametrize('M,N,K', [(4131, 1024, 512), (1000, 256, 128), (264384 // 16, 1024, 512), (300, 512, 64), (257, 264, 64)])
 def test_gemm_nt_gelu_d_and_mul(ops, M, N, K):
     """fc1 + GELU saving the derivative (mbx_gemm_nt_gelu_d) and the one-multiply backward epilogue (mbx_gemm_nt_mul), against the torch
