@@ -70,6 +70,9 @@ int mbx_embed_fwd(const float* x, const float* w, const float* b, const float* p
 size_t mbx_embed_bwd_ws(int T, int J, int Din, int C);
 int mbx_embed_bwd(const float* dh, const float* x, const float* w, float* dw, float* db, float* dpos,
                   float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream);
+/* mbx_embed_bwd with dh = dh_a + dh_b, both bf16 [B*T*J, C] (the input gradients of the two Blocks of level 0; see mbx_fuse_bwd_pair) */
+int mbx_embed_bwd_pair(const void* dh_a, const void* dh_b, const float* x, const float* w, float* dw, float* db, float* dpos,
+                       float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream);
 
 /* ---- LayerNorm (nn.LayerNorm, biased variance, eps inside sqrt; DSTformer.py:221-222,230-231,292)
  * x [M,C] f32 -> y [M,C] T, mean [M], rstd [M].  gamma = beta = NULL: y = (x - mean) rstd (see "LayerNorm folded" below) */

@@ -365,9 +365,19 @@ extern "C" int mbx_embed_fwd(const float* x, const float* w, const float* b, con
 #define EMB_MAXDIN 4
 // 256 threads = (C/4 channel quads) x (256 / (C/4) slices of the clip range); 16-byte loads, eight clips in flight per
 // thread; the slices are folded through LDS.  (The scalar one-clip-at-a-time walk of round 1 took 1.05 ms at 64 clips.)
+// dh_a / dh_b (round 5): the incoming gradient as the sum of two bf16 tensors (the input gradients of the two Blocks of level 0, as
+// their row-owner LayerNorm-backward kernels leave them) instead of one fp32 tensor
+__device__ __forceinline__ float4 embed_dh4(const float* __restrict__ dh, const bf16_t* __restrict__ dh_a, const bf16_t* __restrict__ dh_b, size_t o) {
+    if (dh_a == nullptr) return *reinterpret_cast<const float4*>(dh + o);
+    float u[4], v[4];
+    load4<bf16_t>(dh_a + o, u);
+    load4<bf16_t>(dh_b + o, v);
+    return make_float4(u[0] + v[0], u[1] + v[1], u[2] + v[2], u[3] + v[3]);
+}
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                         float* __restrict__ dtemp, float* __restrict__ part, int B, int T,
-                                                        int J, int Din, int C) {
+                                                        int J, int Din, int C, const bf16_t* __restrict__ dh_a = nullptr,
+                                                        const bf16_t* __restrict__ dh_b = nullptr) {
     __shared__ float4 red[256][1 + EMB_MAXDIN];
     const int t = blockIdx.x;
     const int stride = J * C + C * Din + C;
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int b = min(b0 + u * ns, B - 1);
-                        g[u] = *reinterpret_cast<const float4*>(dh + (((size_t)b * T + t) * J + j) * C + c);
+                        g[u] = embed_dh4(dh, dh_a, dh_b, (((size_t)b * T + t) * J + j) * C + c);
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -442,12 +452,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 }
 // dx[m,k] = sum_c dh[m,c] w[c,k]  (one wave per token)
 __global__ __launch_bounds__(256) void embed_bwd_dx_kernel(const float* __restrict__ dh, const float* __restrict__ w,
-                                                           float* __restrict__ dx, int M, int Din, int C) {
+                                                           float* __restrict__ dx, int M, int Din, int C,
+                                                           const bf16_t* __restrict__ dh_a = nullptr, const bf16_t* __restrict__ dh_b = nullptr) {
     const int lane = threadIdx.x & 63;
     for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
         float a[EMB_MAXDIN] = {0.f, 0.f, 0.f, 0.f};
         for (int c = lane; c < C; c += 64) {
-            const float g = dh[(size_t)m * C + c];
+            const float g = dh_a == nullptr ? dh[(size_t)m * C + c] : bf2f(dh_a[(size_t)m * C + c]) + bf2f(dh_b[(size_t)m * C + c]);
 #pragma unroll
             for (int k = 0; k < EMB_MAXDIN; ++k)
                 if (k < Din) a[k] = fmaf(g, w[(size_t)c * Din + k], a[k]);
@@ -460,25 +471,36 @@ __global__ __launch_bounds__(256) void embed_bwd_dx_kernel(const float* __restri
     }
 }
 extern "C" size_t mbx_embed_bwd_ws(int T, int J, int Din, int C) { return (size_t)T * ((size_t)J * C + (size_t)C * Din + C) * sizeof(float); }
-extern "C" int mbx_embed_bwd(const float* dh, const float* x, const float* w, float* dw, float* db, float* dpos,
-                             float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream) {
-    MBX_CHECK_ARG(dh && x && w && dw && db && dpos && dtemp && ws, "embed_bwd: null pointer");
+static int launch_embed_bwd(const float* dh, const bf16_t* dh_a, const bf16_t* dh_b, const float* x, const float* w, float* dw, float* db,
+                            float* dpos, float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream) {
+    MBX_CHECK_ARG((dh || (dh_a && dh_b)) && x && w && dw && db && dpos && dtemp && ws, "embed_bwd: null pointer");
     MBX_CHECK_ARG(Din <= EMB_MAXDIN, "embed_bwd: dim_in %d > %d unsupported", Din, EMB_MAXDIN);
     MBX_CHECK_ARG(B > 0 && T > 0 && J > 0 && C > 0 && C % 4 == 0, "embed_bwd: bad shape (C %% 4 != 0?)");
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)ws;
     const int stride = J * C + C * Din + C;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(T), dim3(256), 0, s, dh, x, dtemp, part, B, T, J, Din, C);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(T), dim3(256), 0, s, dh, x, dtemp, part, B, T, J, Din, C, dh_a, dh_b);
     MBX_LAUNCH_CHECK("embed_bwd");
     if (mbx_launch_colsum(part, T, stride, 0, J * C, dpos, s)) return 1;
     if (mbx_launch_colsum(part, T, stride, J * C, C * Din, dw, s)) return 1;
     if (mbx_launch_colsum(part, T, stride, J * C + C * Din, C, db, s)) return 1;
     if (dx) {
         const int M = B * T * J;
-        hipLaunchKernelGGL(embed_bwd_dx_kernel, dim3(clamp_grid((M + 3) / 4, 2048)), dim3(256), 0, s, dh, w, dx, M, Din, C);
+        hipLaunchKernelGGL(embed_bwd_dx_kernel, dim3(clamp_grid((M + 3) / 4, 2048)), dim3(256), 0, s, dh, w, dx, M, Din, C, dh_a, dh_b);
         MBX_LAUNCH_CHECK("embed_bwd_dx");
     }
     return 0;
+}
+extern "C" int mbx_embed_bwd(const float* dh, const float* x, const float* w, float* dw, float* db, float* dpos,
+                             float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream) {
+    MBX_CHECK_ARG(dh, "embed_bwd: null pointer");
+    return launch_embed_bwd(dh, nullptr, nullptr, x, w, dw, db, dpos, dtemp, dx, B, T, J, Din, C, ws, stream);
+}
+// the same with dh = dh_a + dh_b, both bf16 [B*T*J, C]
+extern "C" int mbx_embed_bwd_pair(const void* dh_a, const void* dh_b, const float* x, const float* w, float* dw, float* db, float* dpos,
+                                  float* dtemp, float* dx, int B, int T, int J, int Din, int C, void* ws, void* stream) {
+    MBX_CHECK_ARG(dh_a && dh_b, "embed_bwd_pair: null pointer");
+    return launch_embed_bwd(nullptr, (const bf16_t*)dh_a, (const bf16_t*)dh_b, x, w, dw, db, dpos, dtemp, dx, B, T, J, Din, C, ws, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

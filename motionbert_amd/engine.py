@@ -178,12 +178,12 @@ class Engine:
         # beta), no dropout on the branch.  MBX_ROWS_RESID_LN=0: the A/B switch.
         self.rows_resid_ln = (os.environ.get('MBX_ROWS_RESID_LN', '1') == '1' and bool(getattr(ops, 'can_rows_resid_ln', lambda *_: False)(tdtype, cfg)))
         self.Pf: Dict[str, torch.Tensor] = {}       # proj / fc2 weights of those sub-layers in the fragment order of the row-owner kernels
-        # Round 5: the gradient of the residual stream stays in the operand type ACROSS Block boundaries too (levels >= 1): the first
+        # Round 5: the gradient of the residual stream stays in the operand type ACROSS Block boundaries too: the first
         # sub-layer of a Block then also takes the row-owner LayerNorm backward (no row dots, no row constants, bf16 out), and the fusion
         # backward of the level below reads the two Blocks' input gradients as a bf16 pair and adds them (same bytes as one fp32 tensor).
         # Numerics: four realisations on both reference-minted fixtures, every frozen gate (profiles/r05_boundary_numerics.txt).
-        # Level 0 keeps the fp32 gradient for the embedding backward.  MBX_BLOCK_GRAD_T=0: the A/B switch.
-        self.block_grad_t = os.environ.get('MBX_BLOCK_GRAD_T', '1') == '1' and self.rows_lnbwd and hasattr(ops, 'fuse_bwd_pair')
+        # The embedding backward reads level 0's pair the same way (mbx_embed_bwd_pair).  MBX_BLOCK_GRAD_T=0: the A/B switch.
+        self.block_grad_t = os.environ.get('MBX_BLOCK_GRAD_T', '1') == '1' and self.rows_lnbwd and hasattr(ops, 'fuse_bwd_pair') and hasattr(ops, 'embed_bwd_pair')
         # Round 5: with the row means taken by that kernel the GELU' epilogue no longer has to produce the dot of
         # du with the pre-activation, so fc1's forward epilogue saves gelu'(u) -- taken from the fp32 accumulator -- INSTEAD of u (same
         # bytes) and the backward epilogue is one multiply (mbx_gemm_nt_gelu_d / mbx_gemm_nt_mul).  MBX_GELU_D=0: the A/B switch.
@@ -320,10 +320,10 @@ class Engine:
                         for i in range(cfg.depth) for typ, _norm, m, _mode in ORDER[kind][:-1]]
                 self.Pf = dict(zip(lins, ops.rows_n_pack_many([self.Wn[lin] for lin in lins])))
             if need_grad and self.rows_lnbwd and self.gstream_allowed:
-                # (not for the first sub-layer of a Block whose input gradient leaves in fp32 with the other stream's gradient added -- level 0,
-                # or every level with MBX_BLOCK_GRAD_T=0: the tile kernel's epilogue)
+                # (not for the first sub-layer of a Block whose input gradient leaves in fp32 with the other stream's gradient added --
+                # MBX_BLOCK_GRAD_T=0: the tile kernel's epilogue)
                 first = {f'{stream}.{i}.{ORDER[kind][0][2]}.qkv' for stream, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts')) for i in range(cfg.depth)
-                         if i == 0 or not (self.block_grad_t and cfg.att_fuse)}
+                         if not (self.block_grad_t and cfg.att_fuse)}
                 lins = [lin for lin, _ in pairs if lin not in first]
                 self.Pn = dict(zip(lins, ops.rows_n_pack_many([ft[lin] for lin in lins])))
             if self.rawln:
@@ -617,7 +617,7 @@ class Engine:
                 ops.average_bwd(dh, d_st, d_ts, d_st_t, d_ts_t)
             pair = dh = None
             # this level's Blocks hand their input gradients down T-typed when the row-owner tail can take their first sub-layer
-            out_t = bool(self.block_grad_t and self.gstream and cfg.att_fuse and i > 0 and self.M < (1 << 22)
+            out_t = bool(self.block_grad_t and self.gstream and cfg.att_fuse and (i > 0 or self.drop_seed is None) and self.M < (1 << 22)
                          and all(f'{st}.{i}.{ORDER[kind][0][2]}.qkv' in self.Pn for st, kind in (('blocks_st', 'st'), ('blocks_ts', 'ts'))))
             main, side = self._streams()
             if out_t:
@@ -663,8 +663,12 @@ class Engine:
             from .dropmask import site_seed
             ops.dropout(dh, dh, cfg.drop, site_seed(self.drop_seed, -1, 0, 0, 1))
         dx = torch.empty_like(saved['x']) if want_dx else None
-        ops.embed_bwd(dh, saved['x'], P['joints_embed.weight'], G['joints_embed.weight'], G['joints_embed.bias'],
-                      G['pos_embed'], G['temp_embed'], dx, B, T, J)
+        if pair is not None:
+            ops.embed_bwd_pair(pair[0], pair[1], saved['x'], P['joints_embed.weight'], G['joints_embed.weight'], G['joints_embed.bias'],
+                               G['pos_embed'], G['temp_embed'], dx, B, T, J)
+        else:
+            ops.embed_bwd(dh, saved['x'], P['joints_embed.weight'], G['joints_embed.weight'], G['joints_embed.bias'],
+                          G['pos_embed'], G['temp_embed'], dx, B, T, J)
         self._join_wgrads()
         if on_ready is not None:
             on_ready(cfg.depth + 1)

@@ -30,6 +30,7 @@ SIGNATURES = {
     'mbx_embed_fwd': (_i, [_vp] * 6 + [_i] * 5 + [_vp]),
     'mbx_embed_bwd_ws': (_sz, [_i] * 4),
     'mbx_embed_bwd': (_i, [_vp] * 8 + [_i] * 5 + [_vp, _vp]),
+    'mbx_embed_bwd_pair': (_i, [_vp] * 9 + [_i] * 5 + [_vp, _vp]),
     'mbx_layernorm_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mbx_layernorm_bwd_ws': (_sz, [_i]),
     'mbx_layernorm_bwd': (_i, [_vp] * 11 + [_i, _i, _i, _vp, _vp]),
@@ -442,6 +443,14 @@ class HipOps:
         dtemp.zero_()
         self._ck(self.lib.mbx_embed_bwd(_p(dh), _p(x), _p(w), _p(dw), _p(db), _p(dpos), _p(dtemp), _p(dx), B, T, J, Din, Cc,
                                         _p(ws), self._stream()))
+
+    def embed_bwd_pair(self, dh_a, dh_b, x, w, dw, db, dpos, dtemp, dx, B, T, J):
+        """embed_bwd with the incoming gradient as the sum of two bf16 tensors (the two Blocks' input gradients of level 0)."""
+        Din, Cc = x.shape[-1], dh_a.shape[-1]
+        ws = self._ws(('emb', T, J, Din, Cc), self.lib.mbx_embed_bwd_ws, T, J, Din, Cc, device=dh_a.device)
+        dtemp.zero_()
+        self._ck(self.lib.mbx_embed_bwd_pair(_p(dh_a), _p(dh_b), _p(x), _p(w), _p(dw), _p(db), _p(dpos), _p(dtemp), _p(dx), B, T, J, Din, Cc,
+                                             _p(ws), self._stream()))
 
     # ------------------------------------------------------------------ layernorm
     layernorm_fwd_planes_ok = True      # the producers below accept a (hi, lo) pair of bf16 planes where a bf16x3 GEMM operand is due

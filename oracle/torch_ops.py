@@ -183,8 +183,12 @@ class MockOps:
         y = x.reshape(B, T, J, -1) @ w.t() + b + pos.reshape(1, 1, J, -1) + temp[:, :T]
         h.copy_(y.reshape(h.shape))
 
-    def embed_bwd(self, dh, x, w, dw, db, dpos, dtemp, dx, B, T, J):
-        self._log('embed_bwd')
+    def embed_bwd_pair(self, dh_a, dh_b, x, w, dw, db, dpos, dtemp, dx, B, T, J):
+        """mbx_embed_bwd_pair: embed_bwd on dh = dh_a + dh_b (two T-typed tensors)."""
+        self.embed_bwd(dh_a.float() + dh_b.float(), x, w, dw, db, dpos, dtemp, dx, B, T, J, _name='embed_bwd_pair')
+
+    def embed_bwd(self, dh, x, w, dw, db, dpos, dtemp, dx, B, T, J, _name='embed_bwd'):
+        self._log(_name)
         C = dh.shape[-1]
         d4 = dh.reshape(B, T, J, C)
         dw.copy_(dh.t() @ x.reshape(-1, x.shape[-1]))

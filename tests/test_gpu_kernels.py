@@ -81,6 +81,16 @@ def test_embed_fwd_bwd(ops, C):
     MockOps().embed_bwd(dh, x, w, *outs[1], B, T, J)
     for n, a, r in zip(['dw', 'db', 'dpos', 'dtemp', 'dx'], *outs):
         check(f'embed_bwd.{n}.C{C}', a, r, 2e-5)
+    # the incoming gradient as a bf16 pair (round 5: the two Blocks' input gradients of level 0): bit for bit embed_bwd on their fp32 sum
+    dh_a, dh_b = rnd(M, C, seed=7, dtype=torch.bfloat16), rnd(M, C, seed=8, dtype=torch.bfloat16, scale=0.3)
+    pair = [torch.full_like(t, 7.0) for t in outs[0]]
+    ops.embed_bwd_pair(dh_a, dh_b, x, w, *pair, B, T, J)
+    ops.embed_bwd(dh_a.float() + dh_b.float(), x, w, *outs[0], B, T, J)
+    MockOps().embed_bwd_pair(dh_a, dh_b, x, w, *outs[1], B, T, J)
+    torch.cuda.synchronize()
+    for n, a, o, r in zip(['dw', 'db', 'dpos', 'dtemp', 'dx'], pair, *outs):
+        assert torch.equal(a, o), n
+        check(f'embed_bwd_pair.{n}.C{C}', a, r, 2e-5)
 
 
 @pytest.mark.parametrize('dt', TD)

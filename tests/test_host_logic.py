@@ -50,24 +50,25 @@ def test_engine_fp32_matches_reference_gradients(name, fold, rows):
     assert ops.calls.count('prep_weights') == 1 and ops.calls.count('fold_norm_weights') == int(fold)
     assert ops.calls.count('gemm_tn') == 8 * 2 * depth + 1
     rw = fold and rows
-    if rw:      # only the first sub-layer of each Block of LEVEL 0 (st: spatial attention, ts: temporal) keeps the row dots: its input
-        # gradient leaves in fp32 for the embedding backward; everywhere else the row-owner GEMM takes the row means itself and the
-        # gradient crosses the Block boundary in the operand type (the fusion backward below reads the pair)
-        assert ops.calls.count('attn_bwd.0.stats') == ops.calls.count('attn_bwd.1.stats') == 1
-        assert ops.calls.count('attn_bwd.0') == ops.calls.count('attn_bwd.1') == 2 * depth - 1
+    if rw:      # the row-owner GEMM takes the row means itself in every sub-layer, and the gradient crosses the Block boundaries in the
+        # operand type: the fusion backward of the level below / the embedding backward read the two Blocks' gradients as a pair
+        assert ops.calls.count('attn_bwd.0.stats') == ops.calls.count('attn_bwd.1.stats') == 0
+        assert ops.calls.count('attn_bwd.0') == ops.calls.count('attn_bwd.1') == 2 * depth
         assert ops.calls.count('fuse_bwd_pair') == depth - 1 and ops.calls.count('fuse_bwd') == 1
+        assert ops.calls.count('embed_bwd_pair') == 1 and ops.calls.count('embed_bwd') == 0
     else:
         sfx = '.stats' if fold else ''
         assert ops.calls.count('attn_bwd.0' + sfx) == ops.calls.count('attn_bwd.1' + sfx) == 2 * depth
         assert ops.calls.count('fuse_bwd_pair') == 0 and ops.calls.count('fuse_bwd') == depth
+        assert ops.calls.count('embed_bwd_pair') == 0 and ops.calls.count('embed_bwd') == 1
     # folded: the only stand-alone LayerNorm backward left is the final `norm`; every Block LayerNorm runs as a GEMM epilogue
     assert ops.calls.count('layernorm_bwd') == (1 if fold else 8 * depth + 1)
     n_lnbwd = ops.calls.count('gemm_nt.lnbwd') + ops.calls.count('gemm_nt.lnbwd.stream') + ops.calls.count('rows_lnbwd_t')
     assert n_lnbwd == ops.calls.count('unfold_norm_grads') == (8 * depth if fold else 0)
-    assert ops.calls.count('lnbwd_rowc') == ((2 if rw else 8 * depth) if fold else 0)
-    # gradient stream in the operand type: the inner LayerNorm-backward GEMMs of every Block write no fp32 dx (nor the first ones above level 0)
-    assert ops.calls.count('gemm_nt.lnbwd.stream') + ops.calls.count('rows_lnbwd_t') == ((8 * depth - 2 if rw else 6 * depth) if fold else 0)
-    assert ops.calls.count('rows_lnbwd_t') == (8 * depth - 2 if rw else 0)
+    assert ops.calls.count('lnbwd_rowc') == ((0 if rw else 8 * depth) if fold else 0)
+    # gradient stream in the operand type: the inner LayerNorm-backward GEMMs of every Block write no fp32 dx (with the row owners: none does)
+    assert ops.calls.count('gemm_nt.lnbwd.stream') + ops.calls.count('rows_lnbwd_t') == ((8 * depth if rw else 6 * depth) if fold else 0)
+    assert ops.calls.count('rows_lnbwd_t') == (8 * depth if rw else 0)
     # forward: 8 residual GEMMs per level; with the row-owner kernel the six that are followed by a LayerNorm inside their Block bring
     # its output along (three of the four LayerNorm launches of a Block go)
     assert ops.calls.count('rows_resid_ln') == (6 * depth if rw else 0)
