@@ -81,6 +81,38 @@ def test_engine_fp32_matches_reference_gradients(name, fold, rows):
     assert ops.calls.count('gemm_nt.1') == (0 if rw else 4 * depth)      # EPI_GELU
 
 
+@pytest.mark.parametrize('off', ['MBX_BLOCK_GRAD_T', 'MBX_ROWS_RESID_LN', 'MBX_GELU_D', 'MBX_ROWS_LNBWD'])
+def test_round5_switches_one_at_a_time(off, monkeypatch):
+    """Each A/B switch of round 5 off on its own (the others on): same gradients as the reference, and the launch counts of the sequencing
+    it falls back to."""
+    z, cfg = load_golden('tiny_trained')
+    model = build_model(cfg)
+    _load(model, z)
+    model.precision, model.fold_ln = 'fp32', True
+    monkeypatch.setenv(off, '0')
+    ops = MockOps()
+    x = torch.from_numpy(z['x']).requires_grad_(True)
+    out = M.run(ops, model, x)
+    (out * torch.from_numpy(z['cot'])).sum().backward()
+    assert rel_l2(out.detach().numpy(), z['out']) < 2e-6 and rel_l2(x.grad.numpy(), z['dx']) < 2e-5
+    for n, p in model.named_parameters():
+        assert rel_l2(p.grad.numpy(), z['g.' + n]) < 5e-5, n
+    depth = cfg['depth']
+    c = ops.calls.count
+    if off == 'MBX_BLOCK_GRAD_T':       # fp32 across Block boundaries: the first sub-layer of every Block back on the row-dot sequencing
+        assert c('fuse_bwd_pair') == c('embed_bwd_pair') == 0 and c('rows_lnbwd_t') == 6 * depth and c('lnbwd_rowc') == 2 * depth
+        assert c('gemm_nt.gelu_d') == c('rows_resid_ln') * 4 // 6 == 4 * depth
+    elif off == 'MBX_ROWS_RESID_LN':
+        assert c('rows_resid_ln') == 0 and c('gemm_nt.2') == 8 * depth and c('layernorm_fwd') == 8 * depth - 2 * (depth - 1)
+        assert c('rows_lnbwd_t') == 8 * depth and c('gemm_nt.gelu_d') == 4 * depth
+    elif off == 'MBX_GELU_D':
+        assert c('gemm_nt.gelu_d') == c('gemm_nt.mul') == 0 and c('gemm_nt.1') == c('gemm_nt.4') == 4 * depth
+        assert c('rows_lnbwd_t') == 8 * depth and c('rows_resid_ln') == 6 * depth
+    else:                               # no row-owner LayerNorm backward: neither the saved derivative nor the bf16 boundary can follow
+        assert c('rows_lnbwd_t') == c('gemm_nt.gelu_d') == c('fuse_bwd_pair') == c('embed_bwd_pair') == 0
+        assert c('gemm_nt.lnbwd') + c('gemm_nt.lnbwd.stream') == 8 * depth and c('lnbwd_rowc') == 8 * depth and c('rows_resid_ln') == 6 * depth
+
+
 def test_engine_representation_path(golden_dir):
     z, cfg = load_golden('tiny_trained')
     model = build_model(cfg)
