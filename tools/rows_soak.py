@@ -28,6 +28,18 @@ for K in (512, 1024, 1536):
     ops.rows_lnbwd_t(a, pk, xhat, rstd, dres, ref_dx)
     ref = [torch.empty(M, N, device=dev), torch.empty(M, N, device=dev, dtype=BF), torch.empty(M, device=dev), torch.empty(M, device=dev)]
     ops.rows_resid_ln(a, pk, bias, resid, *ref, 1e-6)
+    # spot check of the LAST rows against torch (the kernels address rows with 32-bit byte offsets: the highest ones are at the end)
+    rows = torch.cat([torch.arange(M - 300, M, device=dev), torch.randint(0, M, (300,), device=dev, generator=g)])
+    acc = a[rows].float() @ w.float().t()
+    xh = xhat[rows].float()
+    want_dx = dres[rows].float() + rstd[rows, None] * (acc - acc.mean(-1, keepdim=True) - xh * (acc * xh).mean(-1, keepdim=True))
+    yy = resid[rows] + acc + bias
+    mu = yy.mean(-1, keepdim=True)
+    want_xh = (yy - mu) * torch.rsqrt(((yy - mu) ** 2).mean(-1, keepdim=True) + 1e-6)
+    e = [float((ref_dx[rows].float() - want_dx).norm() / want_dx.norm()), float((ref[0][rows] - yy).norm() / yy.norm()),
+         float((ref[1][rows].float() - want_xh).norm() / want_xh.norm())]
+    print(f'K = {K:4d}: last 300 + 300 random rows against torch: dx {e[0]:.2e}  y {e[1]:.2e}  xhat {e[2]:.2e}', flush=True)
+    bad += int(e[0] > 6e-3 or e[1] > 1e-5 or e[2] > 6e-3)
     dx = torch.empty_like(ref_dx)
     out = [torch.empty_like(t) for t in ref]
     n_bad = [0, 0]
