@@ -1,4 +1,9 @@
-// "N-resident" row-owner GEMM with the LayerNorm backward as its epilogue (round 5): the input gradient of a folded
+// "N-resident" row-owner GEMMs (round 5): one loop, two epilogues that need COMPLETE rows of a 512-column output --
+//   rows_n_lnbwd_kernel     mbx_rows_lnbwd_t    dX of a folded (LayerNorm -> Linear) pair + the LayerNorm backward        (this header)
+//   rows_n_resid_ln_kernel  mbx_rows_resid_ln   proj / fc2 + residual + the NEXT LayerNorm's statistics and xhat           (further down)
+//   rows_n_pack_many_kernel mbx_rows_n_pack_many the weight operand of both as a stream of 1-KiB MFMA fragments
+//
+// The LayerNorm-backward GEMM: the input gradient of a folded
 // (LayerNorm -> Linear) pair INSIDE a Block (reference lib/model/DSTformer.py:241-249: norm1 -> attn.qkv :143, norm2 -> mlp.fc1 :80;
 // the backward of these lines is autograd's in the reference),
 //     dxhat = dY . W'                                   [M, 512] <- [M, K] x [K, 512],  K = 1536 (qkv) or 1024 (fc1)
