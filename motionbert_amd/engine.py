@@ -377,6 +377,13 @@ class Engine:
         main, side = self._streams()
         fuse_ln = cfg.att_fuse and hasattr(ops, 'fuse_ln_fwd')
         ln_st = ln_ts = ln_tail = None      # (xn, mean, rstd) of h already produced by the fusion kernel of the previous level
+        if self.fold and not self.rawln:
+            # folded: both Blocks of a level read the SAME plain normalisation of h (their gamma / beta live in their own weights) -- one
+            # launch for level 0 too, as the fusion kernel provides one xhat for the later levels
+            xn0, mean0, rstd0 = self._op(M, C), self._f(M), self._f(M)
+            ops.layernorm_fwd(h, None, None, cfg.eps, xn0, mean0, rstd0)
+            ln_st = ln_ts = (xn0, mean0, rstd0)
+            del xn0, mean0, rstd0
         for i in range(cfg.depth):
             if side is not None:
                 side.wait_stream(main)
@@ -387,6 +394,7 @@ class Engine:
             else:
                 x_st, sv_st = self._block_fwd(h, f'blocks_st.{i}', 'st', need_grad, ln_st)
                 x_ts, sv_ts = self._block_fwd(h, f'blocks_ts.{i}', 'ts', need_grad, ln_ts)
+            ln_st = ln_ts = None      # consumed; the fusion kernel below may provide the next level's
             hn = self._f(M, C)
             if fuse_ln and not (self.rawln and i + 1 < cfg.depth):      # (no-grad: the next level's consumers read the fp32 rows themselves)
                 # the fusion kernel also normalises its output for its consumers: the first LayerNorm of both blocks of the next
