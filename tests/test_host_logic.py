@@ -114,6 +114,37 @@ def test_round5_switches_one_at_a_time(off, monkeypatch):
         assert c('gemm_nt.lnbwd') + c('gemm_nt.lnbwd.stream') == 8 * depth and c('lnbwd_rowc') == 8 * depth and c('rows_resid_ln') == 6 * depth
 
 
+@pytest.mark.parametrize('name', ['lite_2x81', 'full_1x243'])
+def test_bf16_sequencing_passes_the_fixture_gates_on_cpu(name):
+    """The product's DEFAULT bf16 sequencing (every round-5 switch on: row-owner LayerNorm backward and residual GEMM + LayerNorm, saved
+    GELU derivative, bf16 gradient across Block boundaries) run by the engine over the torch restatement of the kernel set, against the
+    gates of the GPU fixture test (tests/test_gpu_model.py::test_baseline_shape_fixture_fwd_bwd): where a kernel rounds is part of the
+    restatement, so a sequencing change that moves the numerics shows up here without a GPU."""
+    from tests.helpers import trained_like
+    from tests.test_gpu_model import _fixture_grad_errors
+    z, cfg = load_golden(name)
+    names = [str(n) for n in z['names']]
+    ac_per = dict(zip(names, (float(a) for a in z['autocast_grad_per'])))
+    ac_out, ac_glob = float(z['autocast_out']), float(z['autocast_grad_global'])
+    model = build_model(cfg, seed=0)
+    if int(z['trained_seed']) >= 0:
+        trained_like(model, int(z['trained_seed']))
+    model.precision = 'bf16'
+    ops = MockOps()
+    x = torch.from_numpy(z['x']).requires_grad_(True)
+    out = M.run(ops, model, x)
+    (out * torch.from_numpy(z['cot'])).sum().backward()
+    depth = cfg['depth']
+    assert ops.calls.count('rows_lnbwd_t') == 8 * depth and ops.calls.count('rows_resid_ln') == 6 * depth      # the sequencing under test
+    assert ops.calls.count('gemm_nt.gelu_d') == 4 * depth and ops.calls.count('fuse_bwd_pair') == depth - 1 and ops.calls.count('embed_bwd_pair') == 1
+    e_out = rel_l2(out.detach().numpy(), z['out'])
+    e_all, e_worst, worst, e_norm, per = _fixture_grad_errors(model, z)
+    assert e_out < min(2 * ac_out, max(4e-2, ac_out)), (e_out, ac_out)
+    assert e_all < min(2 * ac_glob, max(0.08, ac_glob)), (e_all, ac_glob)
+    bad = {n: round(per[n], 4) for n in names if per[n] > max(3 * ac_per[n], 0.08)}
+    assert not bad, bad
+
+
 def test_engine_representation_path(golden_dir):
     z, cfg = load_golden('tiny_trained')
     model = build_model(cfg)
