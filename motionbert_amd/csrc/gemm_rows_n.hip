@@ -429,6 +429,7 @@ extern "C" int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* 
     MBX_CHECK_ARG(dy && packed && xhat && rstd && dres_t && dx_t, "rows_lnbwd_t: null pointer");
     MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 512 && K % 256 == 0, "rows_lnbwd_t: bad shape M=%d N=%d (512) K=%d (%% 256, >= 512)", M, N, K);
     MBX_CHECK_ARG((size_t)M * RN_N * 2 < ((size_t)1 << 32), "rows_lnbwd_t: M=%d rows of 1 KiB exceed the 32-bit row offsets of the kernel", M);
+    MBX_CHECK_ARG(dx_t != dres_t && dx_t != xhat && dx_t != dy, "rows_lnbwd_t: dx_t aliases an input (rows past M re-read row M - 1 after it was stored)");
     if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_lnbwd_kernel), RN_RING + 4 * 8192, "rows_lnbwd_t")) return 1;
     hipLaunchKernelGGL(rows_n_lnbwd_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)dy,
                        (const char*)packed, (const bf16_t*)xhat, rstd, (const bf16_t*)dres_t, (bf16_t*)dx_t, M, K);
@@ -441,6 +442,7 @@ extern "C" int mbx_rows_resid_ln(const void* a, const void* packed, const float*
     MBX_CHECK_ARG(a && packed && bias && resid && y && xhat && mean && rstd, "rows_resid_ln: null pointer");
     MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 512 && K % 256 == 0, "rows_resid_ln: bad shape M=%d N=%d (512) K=%d (%% 256, >= 512)", M, N, K);
     MBX_CHECK_ARG((size_t)M * RN_N * 4 < ((size_t)1 << 32), "rows_resid_ln: M=%d rows of 2 KiB exceed the 32-bit row offsets of the kernel", M);
+    MBX_CHECK_ARG((const void*)y != (const void*)resid && xhat != a, "rows_resid_ln: y aliases resid (or xhat aliases a): rows past M re-read row M - 1 after it was stored");
     if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_resid_ln_kernel), RN_RING + 4 * 8192, "rows_resid_ln")) return 1;
     hipLaunchKernelGGL(rows_n_resid_ln_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)a,
                        (const char*)packed, bias, resid, y, (bf16_t*)xhat, mean, rstd, eps, M, K);

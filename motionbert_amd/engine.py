@@ -32,7 +32,7 @@ as row constants in its epilogue (mbx_rows_gemm_nk_ln), the MLP as ONE kernel (m
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Dict, List, Optional
+from typing import Any, ClassVar, Dict, List, Optional
 
 import os
 
@@ -71,6 +71,46 @@ class ModelCfg:
     @property
     def hd(self) -> int:
         return self.C // self.H
+
+
+@dataclass(frozen=True)
+class Switches:
+    """The A/B switches of the sequencing: one `MBX_*` environment variable each, every one ON by default except the two marked.
+    They are read ONCE, when this module is imported (`SWITCHES`); a test or a tool that flips one afterwards calls
+    `reload_switches()` (or patches `engine.SWITCHES` with `Switches.from_env({...})`).  What each one selects is described where
+    `Engine.__init__` consumes it."""
+    x3_planes: bool       # MBX_X3_PLANES      bf16x3: producers write the operand planes themselves (0: every operand through mbx_split_bf16)
+    dual_stream: bool     # MBX_DUAL_STREAM    the ts Block of a level on a second HIP stream
+    wgrad_stream: bool    # MBX_WGRAD_STREAM   (default OFF) weight-gradient GEMMs on a third stream
+    fold_ln: bool         # MBX_FOLD_LN        LayerNorm folded into the Linear it feeds (bf16)
+    fold_dx_first: bool   # MBX_FOLD_ORDER     (default OFF) the dX GEMM before the weight gradient
+    grad_stream: bool     # MBX_GRAD_STREAM    gradient of the residual stream in the operand type between sub-layers
+    rows_lnbwd: bool      # MBX_ROWS_LNBWD     row-owner LayerNorm-backward GEMM
+    rows_resid_ln: bool   # MBX_ROWS_RESID_LN  row-owner residual GEMM + next LayerNorm
+    block_grad_t: bool    # MBX_BLOCK_GRAD_T   ... and across Block boundaries
+    gelu_d: bool          # MBX_GELU_D         fc1 saves gelu'(u) instead of u
+    rawln: bool           # MBX_RAWLN          no-grad sequencing (raw-operand LayerNorm + fused MLP)
+    proj_mlp: bool        # MBX_PROJ_MLP       no-grad: proj + residual inside the MLP kernel
+
+    _ENV: ClassVar[tuple] = (('x3_planes', 'MBX_X3_PLANES', '1'), ('dual_stream', 'MBX_DUAL_STREAM', '1'), ('wgrad_stream', 'MBX_WGRAD_STREAM', '0'),
+            ('fold_ln', 'MBX_FOLD_LN', '1'), ('fold_dx_first', 'MBX_FOLD_ORDER', '0'), ('grad_stream', 'MBX_GRAD_STREAM', '1'),
+            ('rows_lnbwd', 'MBX_ROWS_LNBWD', '1'), ('rows_resid_ln', 'MBX_ROWS_RESID_LN', '1'), ('block_grad_t', 'MBX_BLOCK_GRAD_T', '1'),
+            ('gelu_d', 'MBX_GELU_D', '1'), ('rawln', 'MBX_RAWLN', '1'), ('proj_mlp', 'MBX_PROJ_MLP', '1'))
+
+    @classmethod
+    def from_env(cls, env=None) -> 'Switches':
+        env = os.environ if env is None else env
+        return cls(**{field: env.get(var, default) == '1' for field, var, default in cls._ENV})
+
+
+SWITCHES = Switches.from_env()
+
+
+def reload_switches(env=None) -> Switches:
+    """Re-read the MBX_* switches (tests and A/B tools that change the environment after import)."""
+    global SWITCHES
+    SWITCHES = Switches.from_env(env)
+    return SWITCHES
 
 
 # sub-layer order of the two Block flavours (DSTformer.py:240-249)
@@ -126,6 +166,7 @@ class Engine:
 
     def __init__(self, ops, cfg: ModelCfg, P: Dict[str, torch.Tensor], tdtype: torch.dtype, x3: bool = False, drop_seed=None):
         self.ops, self.cfg, self.P, self.T = ops, cfg, P, tdtype
+        sw = SWITCHES      # the A/B switches, read once at import (class Switches)
         # Dropout / DropPath: active only in training with a rate > 0 -- `drop_seed` is then the base seed of this
         # forward pass (None = everything off, the case of every shipped config).  Masks are counter-based (dropmask.py): the
         # element-wise ones and DropPath run as three small kernels around the fused path, the attention-probability dropout
@@ -139,30 +180,30 @@ class Engine:
         # precision 'bf16x3': T-typed tensors are fp32; a tensor that feeds a GEMM is split into (hi, lo) bf16 planes first
         # (`_mm`), and where it ONLY feeds GEMMs (LayerNorm output, GELU output) the planes are what is kept for backward
         self.x3 = x3
-        self.x3_planes = os.environ.get('MBX_X3_PLANES', '1') == '1' and hasattr(ops, 'layernorm_fwd_planes_ok')      # A/B switch: 0 = every operand through mbx_split_bf16
+        self.x3_planes = sw.x3_planes and hasattr(ops, 'layernorm_fwd_planes_ok')      # A/B switch: 0 = every operand through mbx_split_bf16
         self.Wn: Dict[str, torch.Tensor] = {}
         self.Wt: Dict[str, torch.Tensor] = {}
         # The st and ts blocks of a level are independent (DSTformer.py:341-342 feeds both the same x): with
         # MBX_DUAL_STREAM=1 the ts block runs on a second HIP stream so that HBM-bound kernels of one stream
         # (LayerNorm, GEMM epilogues) overlap MFMA-bound kernels of the other.
-        self.dual = os.environ.get('MBX_DUAL_STREAM', '1') == '1' and getattr(ops, 'multi_stream', False)
+        self.dual = sw.dual_stream and getattr(ops, 'multi_stream', False)
         # weight-gradient GEMMs feed nothing downstream in backward: MBX_WGRAD_STREAM=1 issues them on a third stream.  Off by
         # default: 137.0 -> 136.0 ms per step at 64 clips, but the operands stay alive until that stream catches up
         # (record_stream), which at 256 clips (231 GiB resident) sends the allocator into retries: 421 -> 37 clips/s.
-        self.wgrad_async = os.environ.get('MBX_WGRAD_STREAM', '0') == '1'
+        self.wgrad_async = sw.wgrad_stream
         # LayerNorm folding (round 3, bf16 path; include/mbx.h "LayerNorm folded into the Linear it feeds"): the LayerNorm kernels
         # write the plain normalisation xhat, the affine part lives in the qkv / fc1 weights, and the LayerNorm BACKWARD runs as the
         # epilogue of the dX GEMM from row dots the attention-backward / GELU' kernels emit -- 40 LayerNorm-backward launches and the
         # saved fp32 sub-layer inputs disappear.  Off with dropout (the masks sit between the producer and the row dots), in the
         # fp32-class modes (bf16 kernels only), or by request (model.fold_ln = False / MBX_FOLD_LN=0: the A/B switch).
-        self.fold = (os.environ.get('MBX_FOLD_LN', '1') == '1' and not x3 and drop_seed is None and
+        self.fold = (sw.fold_ln and not x3 and drop_seed is None and
                      bool(getattr(ops, 'can_fold', lambda *_: False)(tdtype, cfg)))
-        self.fold_dx_first = os.environ.get('MBX_FOLD_ORDER', '0') == '1'
+        self.fold_dx_first = sw.fold_dx_first
         # Gradient residual stream in the operand type BETWEEN the four sub-layers of a Block (round 4; fp32 at the Block boundaries,
         # fp32 arithmetic in the kernels): the folded LayerNorm-backward GEMM reads its dres as bf16 and writes ONLY the bf16 dx, which
         # is the stream and the next GEMMs' operand at once -- 4 instead of 12 bytes per element and launch.  Numerics:
         # tools/gradstream_numerics.py / profiles/r04_gradstream_numerics.txt (every gate unchanged).  MBX_GRAD_STREAM=0: the A/B switch.
-        self.gstream_allowed = os.environ.get('MBX_GRAD_STREAM', '1') == '1' and bool(getattr(ops, 'grad_stream_t', False))
+        self.gstream_allowed = sw.grad_stream and bool(getattr(ops, 'grad_stream_t', False))
         self.gstream = False      # decided per backward (the folded sequencing only)
         self.Bf: Dict[str, torch.Tensor] = {}
         self.Rs: Dict[str, torch.Tensor] = {}
@@ -170,30 +211,30 @@ class Engine:
         # epilogue of a row-owner GEMM that takes both row means from its own accumulators (mbx_rows_lnbwd_t): the producers of dY --
         # attention backward, the GELU' GEMM -- run WITHOUT their row dots there, and no row-constant launch is needed.  The first
         # sub-layer of a Block (fp32 out, the other block's gradient added) keeps the tile kernel.  MBX_ROWS_LNBWD=0: the A/B switch.
-        self.rows_lnbwd = (os.environ.get('MBX_ROWS_LNBWD', '1') == '1' and bool(getattr(ops, 'can_rows_lnbwd', lambda *_: False)(tdtype, cfg)))
+        self.rows_lnbwd = (sw.rows_lnbwd and bool(getattr(ops, 'can_rows_lnbwd', lambda *_: False)(tdtype, cfg)))
         self.Pn: Dict[str, torch.Tensor] = {}       # transposed folded weights in the fragment order of mbx_rows_lnbwd_t
         # Round 5: the FORWARD residual GEMM (proj / fc2) of a sub-layer that is followed by a LayerNorm runs on the same row-owner shape
         # and leaves the plain normalisation of its output rows with them (mbx_rows_resid_ln): three of the four LayerNorm launches of a
         # Block -- each a second read of the fp32 rows -- disappear.  Folded sequencing only (the kernel writes xhat, not gamma xhat +
         # beta), no dropout on the branch.  MBX_ROWS_RESID_LN=0: the A/B switch.
-        self.rows_resid_ln = (os.environ.get('MBX_ROWS_RESID_LN', '1') == '1' and bool(getattr(ops, 'can_rows_resid_ln', lambda *_: False)(tdtype, cfg)))
+        self.rows_resid_ln = (sw.rows_resid_ln and bool(getattr(ops, 'can_rows_resid_ln', lambda *_: False)(tdtype, cfg)))
         self.Pf: Dict[str, torch.Tensor] = {}       # proj / fc2 weights of those sub-layers in the fragment order of the row-owner kernels
         # Round 5: the gradient of the residual stream stays in the operand type ACROSS Block boundaries too: the first
         # sub-layer of a Block then also takes the row-owner LayerNorm backward (no row dots, no row constants, bf16 out), and the fusion
         # backward of the level below reads the two Blocks' input gradients as a bf16 pair and adds them (same bytes as one fp32 tensor).
         # Numerics: four realisations on both reference-minted fixtures, every frozen gate (profiles/r05_boundary_numerics.txt).
         # The embedding backward reads level 0's pair the same way (mbx_embed_bwd_pair).  MBX_BLOCK_GRAD_T=0: the A/B switch.
-        self.block_grad_t = os.environ.get('MBX_BLOCK_GRAD_T', '1') == '1' and self.rows_lnbwd and hasattr(ops, 'fuse_bwd_pair') and hasattr(ops, 'embed_bwd_pair')
+        self.block_grad_t = sw.block_grad_t and self.rows_lnbwd and hasattr(ops, 'fuse_bwd_pair') and hasattr(ops, 'embed_bwd_pair')
         # Round 5: with the row means taken by that kernel the GELU' epilogue no longer has to produce the dot of
         # du with the pre-activation, so fc1's forward epilogue saves gelu'(u) -- taken from the fp32 accumulator -- INSTEAD of u (same
         # bytes) and the backward epilogue is one multiply (mbx_gemm_nt_gelu_d / mbx_gemm_nt_mul).  MBX_GELU_D=0: the A/B switch.
-        self.gelu_d = (os.environ.get('MBX_GELU_D', '1') == '1' and self.rows_lnbwd and bool(getattr(ops, 'can_gelu_d', lambda *_: False)(tdtype, cfg)))
+        self.gelu_d = (sw.gelu_d and self.rows_lnbwd and bool(getattr(ops, 'can_gelu_d', lambda *_: False)(tdtype, cfg)))
         # no-grad sequencing of a Block (decided per forward): raw-operand LayerNorm + fused MLP, see the module docstring
         self.rawln = False
-        self.rawln_allowed = os.environ.get('MBX_RAWLN', '1') == '1'      # A/B switch: 0 = the training sequencing without saves
+        self.rawln_allowed = sw.rawln      # A/B switch: 0 = the training sequencing without saves
         self.Pk: Dict[str, torch.Tensor] = {}       # fc1 / fc2 of every MLP (with the proj in front of it) in the fragment order of the fused kernels
         self.Pk_proj: Dict[str, str] = {}           # MLP -> the proj Linear packed in front of it (derived from ORDER)
-        self.proj_mlp = os.environ.get('MBX_PROJ_MLP', '1') == '1' and hasattr(ops, 'proj_mlp_fused_fwd')      # A/B switch: 0 = proj + residual as its own GEMM
+        self.proj_mlp = sw.proj_mlp and hasattr(ops, 'proj_mlp_fused_fwd')      # A/B switch: 0 = proj + residual as its own GEMM
 
     def _streams(self):
         """(main, side) streams for the dual-stream schedule, or (None, None)."""
@@ -281,7 +322,9 @@ class Engine:
         in-place update -- optimizer.step(), FlatAdamW, load_state_dict -- bumps them) and everything that selects a format.  None =
         do not cache: a backward follows (training re-prepares every step anyway), or a hipGraph is being captured (the re-pack has
         to be part of the graph so that a replay picks up weights updated in place, graph.py).  Edits through `param.data` bypass the
-        version counters (as they bypass autograd's own checks): `hip_ops.get().weight_cache.clear()` after such an edit."""
+        version counters (as they bypass autograd's own checks); what covers the ordinary train-then-eval loop is that every
+        need_grad forward, `model.train()` and `load_state_dict()` drop the cache (prepare_weights, model.py).  An edit through
+        `.data` in a pure inference process still needs `hip_ops.get().weight_cache.clear()`."""
         if need_grad or not hasattr(self.ops, 'weight_cache') or self.dev.type != 'cuda' or torch.cuda.is_current_stream_capturing():
             return None
         return (tuple((p.data_ptr(), p._version) for p in self.P.values()), self.T, self.fold, self.rawln, self.proj_mlp, self.x3, self.rows_resid_ln)
@@ -292,6 +335,11 @@ class Engine:
         on the kernel provider and reused as long as no parameter changed: an inference call then launches no fold / pack kernels
         (at depth 5 they were ~60 small launches per forward, as many as a B = 1 forward has kernels of its own)."""
         cfg, ops, P = self.cfg, self.ops, self.P
+        if need_grad and hasattr(ops, 'weight_cache') and self.dev.type == 'cuda':
+            # a training step follows: whatever it does to the parameters -- also through `p.data`, which bumps no version counter
+            # (legacy optimizers, EMA code, a replayed graph) -- the next no-grad forward must not find this forward's prepared set
+            # (ADVICE r5).  model.train() / load_state_dict() drop it as well (model.py).
+            ops.weight_cache.pop(self.dev.index, None)
         key = self._weight_cache_key(need_grad)
         if key is not None:
             hit = ops.weight_cache.get(self.dev.index)

@@ -1,15 +1,20 @@
-"""hipGraph replay of the inference forward for latency-bound shapes.
+"""hipGraph capture of the inference forward: a fixed-address replay, NOT a speed-up.
 
-`infer_wild.py:66-88` feeds the backbone one clip at a time (B = 1, T <= 243) and runs it twice per
-clip (flip test-time augmentation).  At that size the ~500 kernel launches of a forward are far
-cheaper on the GPU (about 2 ms) than the Python/ctypes time to issue them (about 15 ms), so the
-launch sequence is captured once into a hipGraph (through torch.cuda.CUDAGraph: every libmbx call
-enqueues on the current stream, the dual-stream fork/join of the engine is captured as graph
-dependencies) and replayed per clip.  Parameters are read at replay time (`prep_weights` is part of
-the graph), so loading new weights into the same storage needs no re-capture; a new input SHAPE does.
+`infer_wild.py:66-88` feeds the backbone one clip at a time (B = 1, T <= 243), twice per clip (flip test-time augmentation).
+Round 1 captured that forward because its ~500 launches cost more Python/ctypes time than GPU time.  Since the no-grad
+sequencing of round 4 (three launches per attention + MLP pair, prepared weights cached between calls) the eager call and
+the replay take the same time at `[1,243,17,3]` (1.5-2.0 ms on the GPU box, DESIGN.md "Host side"): the forward is
+GPU-bound at every shipped size.  The class is kept for callers that want what a graph gives besides speed -- one
+submission per clip, fixed input / output addresses (e.g. to chain it into a larger captured pipeline) -- and its replay
+time is reported by the tests, never asserted.
 
-    fast = GraphedForward(model, example_clip)          # example_clip: [B, T, 17, 3] on the GPU
-    y = fast(clip)                                        # same result as model(clip) under no_grad
+The launch sequence is captured through torch.cuda.CUDAGraph: every libmbx call enqueues on the current stream, the
+dual-stream fork / join of the engine becomes graph dependencies.  Parameters are read at replay time (`prep_weights` is
+part of the graph: engine._weight_cache_key returns None while capturing), so loading new weights into the same storage
+needs no re-capture; a new input SHAPE does.
+
+    fwd = GraphedForward(model, example_clip)           # example_clip: [B, T, 17, 3] on the GPU
+    y = fwd(clip)                                         # same result as model(clip) under no_grad
 """
 from __future__ import annotations
 

@@ -158,11 +158,19 @@ class HipOps:
             return ({n: (hi_n[n], lo_n[n]) for n in names}, {n: (hi_t[n], lo_t[n]) for n in names} if need_t else {})
         return self._prep_weights(P, names, tdtype, need_t, False)
 
+    def _desc_room(self, kind: str, keep: int = 16):
+        """Called under the lock before a descriptor-table entry of `kind` is added: once `keep` of that kind exist (models come and
+        go, operands move) they are dropped -- only that kind, the dict is shared by the three packers."""
+        stale = [k for k in self._desc_cache if k[0] == kind]
+        if len(stale) >= keep:
+            for k in stale:
+                del self._desc_cache[k]
+
     def _prep_weights(self, P, names, tdtype, need_t, lo):
         ws = [P[n + '.weight'] for n in names]
         dev = ws[0].device
         dt = _DT[tdtype]
-        key = (tuple((w.data_ptr(), tuple(w.shape)) for w in ws), dt, dev.index)
+        key = ('prep', tuple((w.data_ptr(), tuple(w.shape)) for w in ws), dt, dev.index)
         with self._lock:
             ent = self._desc_cache.get(key)
             if ent is None:
@@ -172,8 +180,7 @@ class HipOps:
                     rows.append([w.data_ptr(), 0, 0, N, K])
                     offs.append(off)
                     off += N * K
-                if len(self._desc_cache) > 64:
-                    self._desc_cache.clear()
+                self._desc_room('prep')
                 ent = dict(desc=torch.tensor(rows, dtype=torch.int64).to(dev),
                            offs=(torch.tensor(offs, dtype=torch.int64) * torch.empty(0, dtype=tdtype).element_size()).to(dev),
                            offs_host=offs, total=off, max_n=max(w.shape[0] for w in ws), max_k=max(w.shape[1] for w in ws))
@@ -234,8 +241,7 @@ class HipOps:
                     voffs.append(voff)
                     off += N * K
                     voff += N
-                if len(self._desc_cache) > 64:
-                    self._desc_cache.clear()
+                self._desc_room('fold')
                 ent = dict(desc=torch.tensor(rows, dtype=torch.int64).to(dev), offs=(torch.tensor(offs, dtype=torch.int64) * 2).to(dev),
                            voffs=(torch.tensor(voffs, dtype=torch.int64) * 4).to(dev), offs_host=offs, voffs_host=voffs, total=off,
                            vtotal=voff, max_n=max(w.shape[0] for w in ws), max_k=max(w.shape[1] for w in ws))
@@ -351,8 +357,9 @@ class HipOps:
     # ------------------------------------------------------------------ N-resident row-owner GEMM + LayerNorm backward (round 5)
     @staticmethod
     def can_rows_lnbwd(tdtype, cfg) -> bool:
-        """mbx_rows_lnbwd_t exists for bf16, dim_feat = 512 and contraction lengths (3 C, hidden) that are multiples of 256."""
-        return tdtype == torch.bfloat16 and cfg.C == 512 and cfg.hidden % 256 == 0
+        """mbx_rows_lnbwd_t exists for bf16, dim_feat = 512 and contraction lengths (3 C, hidden) that are multiples of 256 and >= 512
+        (one ordinary trip of the loop in front of the peeled last one; mlp_ratio 0.5 falls back to the tile kernels)."""
+        return tdtype == torch.bfloat16 and cfg.C == 512 and cfg.hidden % 256 == 0 and cfg.hidden >= 512
 
     def rows_n_pack(self, w_t):
         """w bf16 [512, K] (the operand of the dX GEMM) in the fragment order of mbx_rows_lnbwd_t / mbx_rows_resid_ln."""
@@ -368,8 +375,14 @@ class HipOps:
         for w in ws:
             if w.shape[0] != 512 or w.shape[1] < 512 or w.shape[1] % 256 or w.dtype != torch.bfloat16 or not w.is_contiguous():
                 raise RuntimeError(f'rows_n_pack_many: operand {tuple(w.shape)} {w.dtype} (bf16 [512, K], K % 256 == 0, K >= 512, contiguous)')
-        base = ws[0].data_ptr()       # (the operands of one call are views into one flat buffer: their relative offsets are what is stable)
-        key = ('rnpack', tuple((w.data_ptr() - base, w.shape[1]) for w in ws), dev.index)
+        # The descriptor table is cached by the operands' offsets from the first one -- stable from step to step when they are views into
+        # ONE flat buffer (prep_weights / fold_norm_weights make them so).  Operands of separate allocations get absolute addresses in
+        # the key instead: still correct, just a cache entry per set of addresses.
+        base = ws[0].data_ptr()
+        store = ws[0].untyped_storage().data_ptr()
+        if any(w.untyped_storage().data_ptr() != store for w in ws):
+            base = 0
+        key = ('rnpack', base == 0, tuple((w.data_ptr() - base, w.shape[1]) for w in ws), dev.index)
         with self._lock:
             ent = self._desc_cache.get(key)
             if ent is None:
@@ -377,8 +390,7 @@ class HipOps:
                 for w in ws:
                     offs.append(off)
                     off += 512 * w.shape[1] * 2
-                if len(self._desc_cache) > 64:
-                    self._desc_cache.clear()
+                self._desc_room('rnpack')
                 ent = dict(desc=torch.tensor([[w.data_ptr() - base, o, w.shape[1]] for w, o in zip(ws, offs)], dtype=torch.int64).to(dev), offs=offs, total=off,
                            max_k=max(w.shape[1] for w in ws))
                 self._desc_cache[key] = ent
@@ -670,4 +682,9 @@ def get() -> HipOps:
         with _OPS_LOCK:
             if _OPS is None:
                 _OPS = HipOps()
+    return _OPS
+
+
+def peek() -> Optional[HipOps]:
+    """The process-wide instance if one has been created, else None (never loads the library: model.train() on a CPU box)."""
     return _OPS

@@ -306,6 +306,26 @@ class DSTformer(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    # ------------------------------------------------------------------ prepared-weight cache of the no-grad path (engine.prepare_weights)
+    @staticmethod
+    def _drop_weight_cache():
+        from . import hip_ops
+        ops = hip_ops.peek()
+        if ops is not None:
+            ops.weight_cache.clear()
+
+    def train(self, mode: bool = True):
+        # entering (or leaving) training: the folded / packed weights kept for inference calls are about to go stale -- also for
+        # updates the version counters do not see (`p.data.add_()`, EMA copies, a replayed hipGraph step): ADVICE r5
+        if mode != self.training:
+            self._drop_weight_cache()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._drop_weight_cache()
+        return out
+
     def get_classifier(self):
         return self.head
 

@@ -53,3 +53,12 @@ def trained_like(model, seed):
                 p.add_((torch.randn(p.shape, generator=g) * 0.2).to(p.device))
             elif n.endswith('bias'):
                 p.add_((torch.randn(p.shape, generator=g) * 0.1).to(p.device))
+
+
+def set_switch(monkeypatch, name: str, value: str):
+    """Flip one MBX_* sequencing switch for the rest of the test: the engine reads them once at import (engine.Switches), so the
+    environment variable AND the module's snapshot are patched; both are restored at teardown."""
+    import os
+    from motionbert_amd import engine
+    monkeypatch.setenv(name, value)
+    monkeypatch.setattr(engine, 'SWITCHES', engine.Switches.from_env(dict(os.environ)))

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from motionbert_amd import model as M
-from tests.helpers import build_model, load_golden, make_input, oracle_cfg, rel_l2, trained_like
+from tests.helpers import build_model, load_golden, make_input, oracle_cfg, rel_l2, set_switch, trained_like
 from tests.mock_ops import MockOps
 
 pytestmark = pytest.mark.gpu
@@ -244,7 +244,7 @@ def test_no_grad_path_on_fixtures(name, monkeypatch):
     ac_out = float(z['autocast_out']) if 'autocast_out' in z.files else TOL_BF16_OUT
     outs = {}
     for raw in ('1', '0'):
-        monkeypatch.setenv('MBX_RAWLN', raw)
+        set_switch(monkeypatch, 'MBX_RAWLN', raw)
         with torch.no_grad():
             model.precision = 'bf16'
             outs[raw] = model(x).float().cpu().numpy()
@@ -253,7 +253,7 @@ def test_no_grad_path_on_fixtures(name, monkeypatch):
         REPORT[f'nograd.{name}.bf16.rawln{raw}'] = dict(out=e_out, rep=e_rep)
         assert e_out < min(2 * ac_out, max(TOL_BF16_OUT, ac_out)), (raw, e_out, ac_out)
     assert rel_l2(outs['1'], outs['0']) < max(TOL_BF16_OUT, ac_out)
-    monkeypatch.setenv('MBX_RAWLN', '1')
+    set_switch(monkeypatch, 'MBX_RAWLN', '1')
     with torch.no_grad():
         model.precision = 'fp32'
         o32 = model(x)
@@ -746,12 +746,16 @@ def test_no_grad_weight_cache_follows_the_parameters():
             assert len(calls) == 3
             other.load_state_dict(sd)
             assert torch.equal(other(x), y2) and len(calls) == 4
-        # a training forward never uses (or fills) the cache
+        # a training step never uses the cache and DROPS it: an update that no version counter sees -- `p.data.mul_()`, what
+        # legacy optimizers and EMA code do -- is picked up by the next no-grad call of an ordinary train-then-eval loop
         other.train()
         other(x).sum().backward()
         assert calls[-1] is True and len(calls) == 5
+        other.blocks_st[0].mlp_s.fc2.weight.data.mul_(1.5)
         other.eval()
         with torch.no_grad():
-            assert torch.equal(other(x), y2) and len(calls) == 5      # the entry of the last no-grad call is still valid: nothing changed
+            y4 = other(x)
+            assert len(calls) == 6 and not torch.equal(y4, y2)
+            assert torch.equal(other(x), y4) and len(calls) == 6      # ... and kept again from then on
     finally:
         engine.Engine._prepare_weights = orig

@@ -187,6 +187,36 @@ def test_rows_resid_ln_rejects_bad_shapes(ops):
         ops.rows_resid_ln(rnd(64, 384, seed=3, dtype=BF), pk, f(512), f(64, 512), f(64, 512), torch.empty(64, 512, device=DEV, dtype=BF), f(64), f(64), 1e-6)   # K % 256
 
 
+def test_rows_kernels_reject_aliased_outputs(ops):
+    """rows past M re-read row M - 1's inputs after its outputs were stored, so an output must not alias the input it is made
+    from -- the entries check it instead of leaving it to the header's fine print."""
+    a, w = rnd(64, 512, seed=1, dtype=BF), rnd(512, 512, seed=2, dtype=BF)
+    pk = ops.rows_n_pack(w)
+    f = lambda *s: torch.empty(*s, device=DEV)
+    resid = f(64, 512)
+    with pytest.raises(RuntimeError):
+        ops.rows_resid_ln(a, pk, f(512), resid, resid, torch.empty(64, 512, device=DEV, dtype=BF), f(64), f(64), 1e-6)      # y is resid
+    dres = rnd(64, 512, seed=3, dtype=BF)
+    with pytest.raises(RuntimeError):
+        ops.rows_lnbwd_t(a, pk, rnd(64, 512, seed=4, dtype=BF), f(64), dres, dres)                                        # dx_t is dres_t
+
+
+def test_rows_n_pack_many_separate_allocations(ops):
+    """operands that are NOT views of one flat buffer (the descriptor cache's offsets would mean nothing) still pack
+    correctly -- absolute addresses in the key -- and the shared descriptor dict keeps the other packers' entries."""
+    ws = [rnd(512, K, seed=10 + K, dtype=BF).clone() for K in (512, 1024)]
+    ops._desc_cache[('fold', 'sentinel')] = dict()
+    try:
+        for _ in range(20):      # more distinct address sets than the cache keeps: only 'rnpack' entries are evicted
+            many = ops.rows_n_pack_many([w.clone() for w in ws])
+        assert ('fold', 'sentinel') in ops._desc_cache
+        assert sum(1 for k in ops._desc_cache if k[0] == 'rnpack') <= 17
+    finally:
+        del ops._desc_cache[('fold', 'sentinel')]
+    for w, pk in zip(ws, many):
+        assert torch.equal(pk, ops.rows_n_pack(w))
+
+
 def test_rows_n_pack_many(ops):
     """One launch packs operands of different contraction lengths; every image equals the one a launch of its own makes, the fragment
     layout is the documented one (fragment (kk, nt), lane (i, g): w[32 nt + i][16 kk + 8 g .. + 7]), and a second call with the same

@@ -12,7 +12,7 @@ import os
 import torch
 
 from motionbert_amd import model as M
-from tests.helpers import build_model, load_golden, rel_l2
+from tests.helpers import build_model, load_golden, rel_l2, set_switch
 from tests.mock_ops import MockOps
 
 
@@ -90,7 +90,7 @@ def test_round5_switches_one_at_a_time(off, monkeypatch):
     model = build_model(cfg)
     _load(model, z)
     model.precision, model.fold_ln = 'fp32', True
-    monkeypatch.setenv(off, '0')
+    set_switch(monkeypatch, off, '0')
     ops = MockOps()
     x = torch.from_numpy(z['x']).requires_grad_(True)
     out = M.run(ops, model, x)
@@ -200,7 +200,7 @@ def test_no_grad_saves_nothing_and_frozen_params_get_none():
 
 
 @pytest.mark.parametrize('name', ['tiny_default', 'tiny_trained'])
-def test_no_grad_raw_operand_sequencing(name):
+def test_no_grad_raw_operand_sequencing(name, monkeypatch):
     """The no-grad path of a Block: 3 launches per attention + MLP pair -- qkv as a row-owner GEMM that makes operand and LayerNorm
     statistics from the fp32 rows (rows_gemm.ln), attention, and ONE kernel for proj + residual + LayerNorm + fc1 + GELU + fc2 + residual
     -- no LayerNorm pass, no bf16 copy of the residual stream; against the reference output and against the training-path sequencing."""
@@ -224,13 +224,11 @@ def test_no_grad_raw_operand_sequencing(name):
     assert ops.calls.count('rows_gemm.ln') == ops.calls.count('rows_pack_nk') == 4 * depth
     assert ops.calls.count('gemm_nt.2') == 0                                          # no stand-alone proj + residual GEMM
     # the three-kernel form (proj + residual as its own GEMM, then the fused MLP on its fp32 output) behind the A/B switch
-    os.environ['MBX_PROJ_MLP'] = '0'
-    try:
-        ops3 = MockOps()
-        with torch.no_grad():
-            out3 = M.run(ops3, model, x)
-    finally:
-        del os.environ['MBX_PROJ_MLP']
+    set_switch(monkeypatch, 'MBX_PROJ_MLP', '0')
+    ops3 = MockOps()
+    with torch.no_grad():
+        out3 = M.run(ops3, model, x)
+    set_switch(monkeypatch, 'MBX_PROJ_MLP', '1')
     assert rel_l2(out3.numpy(), z['out']) < 5e-6
     assert ops3.calls.count('mlp_fused_fwd.from_x') == ops3.calls.count('mlp_pack_weights') == 4 * depth and ops3.calls.count('gemm_nt.2') == 4 * depth
     assert ops.calls.count('gemm_nt.0') == ops.calls.count('gemm_nt.1') == 0          # no qkv / fc1 / fc2 launches of the training path

@@ -11,7 +11,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from motionbert_amd import model as M                      # noqa: E402
+from motionbert_amd import engine, model as M              # noqa: E402
 from oracle.torch_ops import MockOps                       # noqa: E402
 from tests.helpers import build_model, load_golden, rel_l2, trained_like   # noqa: E402
 from tests.test_gpu_model import _fixture_grad_errors      # noqa: E402
@@ -26,6 +26,7 @@ ac_out, ac_glob = float(z['autocast_out']), float(z['autocast_grad_global'])
 for pseed in (0, 1, 2, 3):
     for tag, sw in (('fp32 across Block boundaries', '0'), ('bf16 across Block boundaries', '1')):
         os.environ['MBX_BLOCK_GRAD_T'] = sw
+        engine.reload_switches()      # (the switches are read once at import)
         model = build_model(cfg, seed=0)
         if int(z['trained_seed']) >= 0:
             trained_like(model, int(z['trained_seed']))
