@@ -26,7 +26,7 @@ GPU box, so its inputs/outputs/gradients are committed as small .npz fixtures:
       (l2, sum) of every parameter gradient, the FULL gradient of every tensor
       with <= 16384 elements and a fixed 4096-element sample of every larger one,
       plus the error of the reference ITSELF under torch.autocast(bfloat16)
-      against its fp64 run (output, global gradient, per tensor): the yardstick
+      against its fp64 run (output, input gradient, global gradient, per tensor): the yardstick
       the bf16 mode of the HIP path is gated against.
 
 While generating, the numpy oracle is checked against the reference (fp64
@@ -213,6 +213,7 @@ def baseline_shape(DST, name, kw, B, T, trained_seed):
         o16 = m16(x16)
     (o16.float() * cot).sum().backward()
     g16 = {n: p.grad.detach().numpy().copy() for n, p in m16.named_parameters()}
+    dx16 = x16.grad.detach().numpy().copy()
     # fp32 reference (its own round-off against fp64 is the floor of the 1e-3 gate)
     m32 = copy.deepcopy(model)
     o32 = m32(x)
@@ -224,15 +225,29 @@ def baseline_shape(DST, name, kw, B, T, trained_seed):
     ac_global, ac_per = grad_error_table(g16, grads, names)
     f32_global, f32_per = grad_error_table(g32, grads, names)
     ac_out = O.rel_l2(o16.detach().float().numpy(), out)
-    print(f'[{name}] reference under autocast(bf16) vs fp64: out {ac_out:.2e}  grad global {ac_global:.2e}  worst tensor '
+    ac_dx = O.rel_l2(dx16, dx)      # (round 6) the yardstick of the bf16 INPUT gradient, which had no gate of its own
+    print(f'[{name}] reference under autocast(bf16) vs fp64: out {ac_out:.2e}  dx {ac_dx:.2e}  grad global {ac_global:.2e}  worst tensor '
           f'{ac_per.max():.2e} ({names[int(ac_per.argmax())]});  fp32 vs fp64: out {O.rel_l2(o32.detach().numpy(), out):.2e} '
           f'grad global {f32_global:.2e} worst {f32_per.max():.2e}')
     save = dict(x=x.numpy(), cot=cot.numpy(), out=out, dx=dx.astype(np.float32), names=np.asarray(names),
                 trained_seed=np.asarray(-1 if trained_seed is None else trained_seed),
                 w_stats=np.asarray([[sd32[k].astype(np.float64).sum(), np.abs(sd32[k].astype(np.float64)).sum()] for k in names]),
                 g_stats=np.asarray([[np.linalg.norm(grads[k]), grads[k].sum()] for k in names]),
-                autocast_out=np.asarray(ac_out), autocast_grad_global=np.asarray(ac_global), autocast_grad_per=ac_per,
+                autocast_out=np.asarray(ac_out), autocast_dx=np.asarray(ac_dx), autocast_grad_global=np.asarray(ac_global), autocast_grad_per=ac_per,
                 fp32_out=np.asarray(O.rel_l2(o32.detach().numpy(), out)), fp32_grad_global=np.asarray(f32_global), fp32_grad_per=f32_per)
+    # The autocast yardsticks are ONE realisation of the reference's bf16 rounding noise and differ from run to run with the thread
+    # count and the torch build (full_1x243, global gradient: 0.217 when the fixture was first minted in round 1, 0.107 in round 6;
+    # everything fp64 in the fixture re-derives bit for bit).  The bf16 gates of tests/test_gpu_model.py are multiples of these
+    # numbers and are frozen, so a yardstick that is already in the committed fixture is KEPT; a re-run only adds what is missing
+    # (round 6: autocast_dx).  MBX_REFRESH_YARDSTICK=1 overwrites them.
+    old_path = os.path.join(ROOT, 'tests/golden', f'{name}.npz')
+    if os.path.exists(old_path) and os.environ.get('MBX_REFRESH_YARDSTICK', '0') != '1':
+        with np.load(old_path) as old:
+            for k in ('autocast_out', 'autocast_dx', 'autocast_grad_global', 'autocast_grad_per'):
+                if k in old.files:
+                    if not np.array_equal(old[k], save[k]):
+                        print(f'[{name}] keeping the committed {k} = {float(np.max(old[k])):.4g} (this run: {float(np.max(save[k])):.4g})')
+                    save[k] = old[k]
     for k in names:
         g = grads[k].reshape(-1)
         if g.size <= SAMPLE_FULL_BELOW:

@@ -34,6 +34,7 @@ TOL_BF16_GRAD = 6e-2     # global relative L2 over all parameter gradients in bf
 #   bf16: global gradient                                                    < min(2 x autocast, max(0.08, autocast)) aaabbfb (round 2)
 #   bf16: per-tensor gradient                                                <= max(3 x autocast, 0.08 of the global norm)   def31fb (round 3: 0.05 -> 0.08
 #                                                                              with LayerNorm folding, profiles/r03_fold_numerics.txt)
+#   bf16: input gradient (round 6, NEW: it was recorded and never asserted) < min(2 x autocast_dx, max(0.08, autocast_dx))  round 6 (the form of the global-gradient gate)
 #   bf16x3 per tensor, chaotic oracle case / recompute fixtures              3e-3                                    347c9a1 / 7ad8d74 (round 2 / 3)
 #   bf16 on the chaotic oracle case                                          out < 0.0778, global gradient < 1.509   fc24144 (round 2: the
 #                                                                              reference's own autocast error on that configuration)
@@ -222,6 +223,17 @@ def test_baseline_shape_fixture_fwd_bwd(name, precision, recompute):
         # global norm; the relative part (3x the reference's own autocast error) stays.
         bad = {n: (per[n], float(a)) for n, a in zip(names, z['autocast_grad_per']) if per[n] > max(3 * float(a), 0.08)}
         assert not bad, f'bf16 per-tensor gradient error above max(3x the reference-under-autocast error, 8 % of the global norm): {bad}'
+        # Round 6: the INPUT gradient gets the gate every other bf16 quantity has -- against the reference's own
+        # autocast error on dx, minted into the fixture by oracle/make_golden.py (autocast_dx; lite_2x81 0.0085, full_1x243 0.156).
+        ac_dx = float(z['autocast_dx'])
+        assert e_dx < min(2 * ac_dx, max(0.08, ac_dx)), (e_dx, ac_dx)
+        # measured value / gate for every frozen bf16 gate (profiles/r06_bf16_headroom.txt is printed from these): the next rounding
+        # that is "inside the spread" has a number to be inside of
+        worst_ratio, worst_t = max((per[n] / max(3 * float(a), 0.08), n) for n, a in zip(names, z['autocast_grad_per']))
+        REPORT[f'headroom.{name}.bf16' + ('.recompute' if recompute else '')] = dict(
+            out=(e_out, min(2 * ac['out'], max(TOL_BF16_OUT, ac['out']))), dx=(e_dx, min(2 * ac_dx, max(0.08, ac_dx))),
+            grad_global=(e_all, min(2 * ac['grad_global'], max(0.08, ac['grad_global']))),
+            per_tensor_worst=(per[worst_t], max(3 * float(dict(zip(names, z['autocast_grad_per']))[worst_t]), 0.08), worst_t), per_tensor_worst_ratio=worst_ratio)
 
 
 @pytest.mark.parametrize('name', ['tiny_trained', 'lite_2x81', 'full_1x243'])

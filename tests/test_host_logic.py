@@ -141,6 +141,8 @@ def test_bf16_sequencing_passes_the_fixture_gates_on_cpu(name):
     e_all, e_worst, worst, e_norm, per = _fixture_grad_errors(model, z)
     assert e_out < min(2 * ac_out, max(4e-2, ac_out)), (e_out, ac_out)
     assert e_all < min(2 * ac_glob, max(0.08, ac_glob)), (e_all, ac_glob)
+    e_dx, ac_dx = rel_l2(x.grad.numpy(), z['dx']), float(z['autocast_dx'])      # (round 6) the input gradient, gated like the rest
+    assert e_dx < min(2 * ac_dx, max(0.08, ac_dx)), (e_dx, ac_dx)
     bad = {n: round(per[n], 4) for n in names if per[n] > max(3 * ac_per[n], 0.08)}
     assert not bad, bad
 
