@@ -29,6 +29,18 @@
 #include "mbx_common.h"
 #include "lds_stream.h"
 
+#ifndef MBX_RN_DBG
+#define MBX_RN_DBG 0        // ablation bits of diagnostic builds (timing only, results wrong): 1 no epilogue, 2 no loop (prologue + epilogue only)
+#endif
+// Diagnostic builds only (-DMBX_RN_TRACE, tools/rn_trace.py): 12 int64 per workgroup of the LayerNorm-backward kernel (wave 0, lane 0) --
+// s_memrealtime (100 MHz) at entry, first stage landed, end of the loop, after the drain + barrier, after xhat -> LDS, after pass 1,
+// after each quarter of pass 2 (stores issued), stores acknowledged.  The buffer address comes from the environment variable MBX_TRACE_BUF.
+#ifdef MBX_RN_TRACE
+__device__ long long* g_rn_trace;
+#define RN_TS(slot_) do { tsr[slot_] = (long long)wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)      // (kept in scalar registers until the end)
+#else
+#define RN_TS(slot_) do { } while (0)
+#endif
 static constexpr int RN_BM = 128;              // token rows per workgroup (4 waves x 32)
 static constexpr int RN_N = 512;               // output columns = the accumulators of a wave (16 tiles of 32)
 static constexpr int RN_STAGE = 32 * 1024;     // one ring stage = 32 fragments = 2 k-steps x 16 column tiles
@@ -66,6 +78,10 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
                                                              const bf16_t* __restrict__ dres_t, bf16_t* __restrict__ dx_t, int M, int K) {
     constexpr int PF = 5;
     extern __shared__ __attribute__((aligned(16))) char ring[];
+#ifdef MBX_RN_TRACE
+    long long tsr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RN_TS(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
     const int mw = blockIdx.x * RN_BM + 32 * wave;
@@ -76,10 +92,13 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     // stage q of the stream (past the end: a harmless re-read of the last stage into a slot nobody reads again)
 #define RN_ISSUE(q_, j_) glds16_s(wpk + (size_t)min((q_), nstages - 1) * RN_STAGE + (j_) * 4096, wvo, dl + ((q_) & 3) * RN_STAGE + (j_) * 4096)
     // token fragments: lane (i, g) = 16 bytes of row i at k = 16 s + 8 g; rows past M repeat row M - 1 (their results are never stored)
-    const char* ap = reinterpret_cast<const char*>(dy + (size_t)min(mw + i, M - 1) * K + 8 * g);
+    // (round 6: a wave-uniform 64-bit base that moves from trip to trip + ONE 32-bit lane offset, instead of two 64-bit lane pointers --
+    // three registers for a loop that has none to spare; the C entries check M K 2 < 2^32)
+    const char* ap = reinterpret_cast<const char*>(dy);
+    const unsigned aoff = ((unsigned)min(mw + i, M - 1) * (unsigned)K + 8u * g) * 2u;
     u32x4_t tok[16];                               // fragment s lives in tok[s & 15]
-#define RN_TOK(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst_) : "v"(ap), "n"(off_) : "memory")
-#define RN_TOKN(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst_) : "v"(apn), "n"(off_) : "memory")
+#define RN_TOK(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst_) : "v"(aoff), "s"(ap), "n"(off_) : "memory")
+#define RN_TOKN(dst_, off_) RN_TOK(dst_, (off_) + 512)      /* the tokens of the next trip's first half */
     RN_TOK(tok[0], 0); RN_TOK(tok[1], 32); RN_TOK(tok[2], 64); RN_TOK(tok[3], 96);
     RN_TOK(tok[4], 128); RN_TOK(tok[5], 160); RN_TOK(tok[6], 192); RN_TOK(tok[7], 224);
 #pragma unroll
@@ -99,6 +118,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    RN_TS(1);
     u32x4_t fb[8];
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
@@ -118,7 +138,6 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
 #define RN_XLD(n_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr_[n_]) : "v"(xoff[(n_) & 7]), "s"(xhat), "n"(((n_) >> 3) * 256) : "memory")
 #define RN_TRIP(LAST_, XPF_)                                                                                             \
     {                                                                                                                \
-        const char* const apn = ap + 512;                   /* where the tokens of the next trip's first half are */                   \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                              \
             const int q = q0 + u;                                                                                    \
             unsigned st = fr + (u & 3) * RN_STAGE, sn = fr + ((u + 1) & 3) * RN_STAGE;                               \
@@ -154,10 +173,15 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
         ap += 512;                                                                                                   \
     }
     int q0 = 0;
-    for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, true)
-    RN_TRIP(true, true)
+    if (!(MBX_RN_DBG & 2)) {
+        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, true)
+        RN_TRIP(true, true)
+    }
+    RN_TS(2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the re-read tail stages, the over-read tokens and xhat have landed
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring: 32 KiB of it per wave are buffers now
+    RN_TS(3);
+    if (MBX_RN_DBG & 1) return;
 #pragma unroll
     for (int t = 0; t < 16; ++t) MFMA_PAD_A(acc[t]);
 #pragma unroll
@@ -201,12 +225,26 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     const float rs = rstd[min(mw + i_e, M - 1)];
     float c1 = 0.f, c2 = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the rows a lane reads were written by other lanes of THIS wave: in order)
+    RN_TS(4);
+    // (round 6: the four reads of tile nt + 1 are issued in front of the arithmetic of tile nt.  One wave per SIMD means nothing else
+    // covers a ds_read -> use pair: as written in round 5 every tile of both passes waited out its own LDS round trip, 228 s_waitcnt in
+    // 2700 VALU instructions -- profiles/r06_rows_n_ablation.txt)
+    const char* const ex = eb + i_e * 256 + 8 * g_e;
+    const int sx = (i_e & 15) << 4;
+#define RN_XRD(nt_, qq_) (*reinterpret_cast<const uint2*>(ex + ((nt_) >> 2) * 8192 + (((((nt_) & 3) * 4 + (qq_)) << 4) ^ sx)))
+    uint2 xq[2][4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) xq[0][qq] = RN_XRD(0, qq);
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) {
+        if (nt + 1 < 16) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) xq[(nt + 1) & 1][qq] = RN_XRD(nt + 1, qq);
+        }
         const f32x16_t t = acc[nt];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            const uint2 xv = *reinterpret_cast<const uint2*>(eb + (nt >> 2) * 8192 + i_e * 256 + ((((nt & 3) * 4 + qq) ^ (i_e & 15)) << 4) + 8 * g_e);
+            const uint2 xv = xq[nt & 1][qq];
             const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
             const float x2 = __uint_as_float(xv.y << 16), x3 = __uint_as_float(xv.y & 0xffff0000u);
             c1 += (t[4 * qq] + t[4 * qq + 1]) + (t[4 * qq + 2] + t[4 * qq + 3]);
@@ -217,19 +255,28 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     c1 = wave_halves<WaveAdd>(c1) * (1.0f / (float)RN_N);             // the two halves of row i: lanes i and i + 32
     c2 = wave_halves<WaveAdd>(c2) * (1.0f / (float)RN_N);
     const float k1 = -rs * c1, k2 = -rs * c2;                         // dx = dres + rs t + k1 + k2 xhat
+    RN_TS(5);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // vector memory operations younger than the DMA of quarter j: the stores of quarter j - 1 (8)
         if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const char* const dx_ = bd + i_e * 256 + 8 * g_e;
+#define RN_DRD(ntl_, qq_) (*reinterpret_cast<const uint2*>(dx_ + ((((ntl_) * 4 + (qq_)) << 4) ^ sx)))
+        uint2 xp2[2][4], dp2[2][4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) { xp2[0][qq] = RN_XRD(4 * j, qq); dp2[0][qq] = RN_DRD(0, qq); }
 #pragma unroll
         for (int ntl = 0; ntl < 4; ++ntl) {
+            if (ntl + 1 < 4) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) { xp2[(ntl + 1) & 1][qq] = RN_XRD(4 * j + ntl + 1, qq); dp2[(ntl + 1) & 1][qq] = RN_DRD(ntl + 1, qq); }
+            }
             const f32x16_t t = acc[4 * j + ntl];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const int off = i_e * 256 + (((ntl * 4 + qq) ^ (i_e & 15)) << 4) + 8 * g_e;
-                uint2* const p = reinterpret_cast<uint2*>(eb + j * 8192 + off);
-                const uint2 xv = *p;
-                const uint2 dv = *reinterpret_cast<const uint2*>(bd + off);
+                uint2* const p = reinterpret_cast<uint2*>(eb + j * 8192 + i_e * 256 + 8 * g_e + (((ntl * 4 + qq) << 4) ^ sx));
+                const uint2 xv = xp2[ntl & 1][qq];
+                const uint2 dv = dp2[ntl & 1][qq];
                 const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
                 const float d2 = __uint_as_float(dv.y << 16), d3 = __uint_as_float(dv.y & 0xffff0000u);
                 const float x0 = __uint_as_float(xv.x << 16), x1 = __uint_as_float(xv.x & 0xffff0000u);
@@ -250,7 +297,18 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             // and every wave issues the same number of vector memory instructions -- the counted waits above depend on it
             *reinterpret_cast<uint4*>(dx_t + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp_e ^ (rl & 15)) << 3)) = v;
         }
+        RN_TS(6 + j);
     }
+#ifdef MBX_RN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RN_TS(10);
+    if (g_rn_trace != nullptr && threadIdx.x == 0) {
+        long long* const tr = g_rn_trace + (size_t)blockIdx.x * 12;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) tr[k] = tsr[k];
+        tr[11] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+#endif
 }
 
 // ---- the same product as the FORWARD residual GEMM of a sub-layer that is followed by a LayerNorm (round 5):
@@ -281,7 +339,8 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
     const unsigned dlu = __builtin_amdgcn_readfirstlane(dl);
     const int nstages = K / 32;
-    const char* ap = reinterpret_cast<const char*>(a + (size_t)min(mw + i, M - 1) * K + 8 * g);
+    const char* ap = reinterpret_cast<const char*>(a);
+    const unsigned aoff = ((unsigned)min(mw + i, M - 1) * (unsigned)K + 8u * g) * 2u;
     // the wave's copy of the bias (8 floats per lane), requested first -- the oldest vector memory operations of the kernel, so no
     // counted wait below changes -- and parked in the wave's fifth buffer after the loop (the wait there carries the dependence)
     u32x4_t bq0, bq1;
@@ -316,10 +375,13 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
 #undef RN_XLD
 #define RN_XLD(n_) ((void)0)
     int q0 = 0;
-    for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
-    RN_TRIP(true, false)
+    if (!(MBX_RN_DBG & 2)) {
+        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
+        RN_TRIP(true, false)
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bq0), "+v"(bq1) : : "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
+    if (MBX_RN_DBG & 1) return;
 #pragma unroll
     for (int t = 0; t < 16; ++t) MFMA_PAD_A(acc[t]);
 
@@ -429,8 +491,15 @@ extern "C" int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* 
     MBX_CHECK_ARG(dy && packed && xhat && rstd && dres_t && dx_t, "rows_lnbwd_t: null pointer");
     MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 512 && K % 256 == 0, "rows_lnbwd_t: bad shape M=%d N=%d (512) K=%d (%% 256, >= 512)", M, N, K);
     MBX_CHECK_ARG((size_t)M * RN_N * 2 < ((size_t)1 << 32), "rows_lnbwd_t: M=%d rows of 1 KiB exceed the 32-bit row offsets of the kernel", M);
+    MBX_CHECK_ARG((size_t)M * K * 2 < ((size_t)1 << 32), "rows_lnbwd_t: dy of M=%d x K=%d exceeds the 32-bit lane offsets of the kernel", M, K);
     MBX_CHECK_ARG(dx_t != dres_t && dx_t != xhat && dx_t != dy, "rows_lnbwd_t: dx_t aliases an input (rows past M re-read row M - 1 after it was stored)");
     if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_lnbwd_kernel), RN_RING + 4 * 8192, "rows_lnbwd_t")) return 1;
+#ifdef MBX_RN_TRACE
+    {
+        static long long* const tb = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rn_trace), &tb, sizeof(tb), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
+    }
+#endif
     hipLaunchKernelGGL(rows_n_lnbwd_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)dy,
                        (const char*)packed, (const bf16_t*)xhat, rstd, (const bf16_t*)dres_t, (bf16_t*)dx_t, M, K);
     MBX_LAUNCH_CHECK("rows_lnbwd_t");
@@ -442,6 +511,7 @@ extern "C" int mbx_rows_resid_ln(const void* a, const void* packed, const float*
     MBX_CHECK_ARG(a && packed && bias && resid && y && xhat && mean && rstd, "rows_resid_ln: null pointer");
     MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 512 && K % 256 == 0, "rows_resid_ln: bad shape M=%d N=%d (512) K=%d (%% 256, >= 512)", M, N, K);
     MBX_CHECK_ARG((size_t)M * RN_N * 4 < ((size_t)1 << 32), "rows_resid_ln: M=%d rows of 2 KiB exceed the 32-bit row offsets of the kernel", M);
+    MBX_CHECK_ARG((size_t)M * K * 2 < ((size_t)1 << 32), "rows_resid_ln: a of M=%d x K=%d exceeds the 32-bit lane offsets of the kernel", M, K);
     MBX_CHECK_ARG((const void*)y != (const void*)resid && xhat != a, "rows_resid_ln: y aliases resid (or xhat aliases a): rows past M re-read row M - 1 after it was stored");
     if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_resid_ln_kernel), RN_RING + 4 * 8192, "rows_resid_ln")) return 1;
     hipLaunchKernelGGL(rows_n_resid_ln_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)a,
