@@ -96,6 +96,23 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     // three registers for a loop that has none to spare; the C entries check M K 2 < 2^32)
     const char* ap = reinterpret_cast<const char*>(dy);
     const unsigned aoff = ((unsigned)min(mw + i, M - 1) * (unsigned)K + 8u * g) * 2u;
+    // xhat, the epilogue's first input, is requested DURING the loop, by LDS-DMA (round 6; round 5 loaded it into 128 registers in the
+    // last trip and wrote them to LDS after the loop: 2 us per tile in situ, profiles/r06_rn_trace.txt).  Piece n = 8 j + r4 = rows
+    // 4 r4 .. 4 r4 + 3 of quarter j (128 columns = 256 bytes per row); lane (xr, xp) fetches the 16-byte piece xp ^ (row & 15) of row
+    // 4 r4 + xr, so that piece p of row r lands in slot p ^ (r & 15) of its row.  Pieces 26..31 (quarter 3, r4 = 2..7) go into the wave's
+    // fifth buffer HERE -- the oldest vector memory operations of the kernel, so no counted wait below changes; pieces 0..25 take the 26
+    // slots of the last trip in which the stream has nothing left to fetch (RN_TRIP) and land in the wave's KiB of ring slot n >> 3,
+    // piece n & 7 -- each freed by the barrier in front of the slot that refills it.
+    const int xr = lane >> 4, xp = lane & 15;
+    unsigned xoff[8];                              // byte offset of (row 4 r4 + xr, piece xp ^ (row & 15) of quarter 0) in xhat / dres / dx
+#pragma unroll
+    for (int r4 = 0; r4 < 8; ++r4) xoff[r4] = (unsigned)min(mw + 4 * r4 + xr, M - 1) * (RN_N * 2) + ((xp ^ ((4 * r4 + xr) & 15)) << 4);
+    {
+        const unsigned bdl0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const lds_void_t*)ring + RN_RING + wave * 8192);
+#pragma unroll
+        for (int r4 = 2; r4 < 8; ++r4) glds16_s(reinterpret_cast<const char*>(xhat) + 3 * 256, xoff[r4], bdl0 + r4 * 1024);
+    }
+#define RN_DPIECE(n_, sp_) rn_glds(reinterpret_cast<const char*>(xhat) + ((n_) >> 3) * 256, xoff[(n_) & 7], dlu, sp_)
     u32x4_t tok[16];                               // fragment s lives in tok[s & 15]
 #define RN_TOK(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst_) : "v"(aoff), "s"(ap), "n"(off_) : "memory")
 #define RN_TOKN(dst_, off_) RN_TOK(dst_, (off_) + 512)      /* the tokens of the next trip's first half */
@@ -123,20 +140,11 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
     // ---- the product: trips of 8 stages = 16 k-steps (the token ring's indices are then static); K % 256 == 0, K >= 512.
-    // The LAST trip also requests the wave's 32 x 512 slice of xhat, row-major, into registers (four loads per stage in slots 24, 26, 28,
-    // 30: instruction n = 8 j + r4 = rows 4 r4 + xr, 16-byte piece xp of quarter j), so that the epilogue's first input is on chip when
-    // the loop ends -- the per-CU miss bandwidth (~11 B/clk) is what an epilogue costs that starts its loads only then
-    // (v1 of this kernel: 19 us per tile for 384 KiB).  Counted waits of the last trip: a stage issues 8 P + 4 X and, in its first half,
-    // 2 T (there is no next trip to fetch tokens for); the barrier of its stage u sees 23 (u = 0: the two stages before belong to an
-    // ordinary trip), 27, 31, 31, 30, 28, 26, 26 younger operations.
-    u32x4_t xr_[32];
-    const int xr = lane >> 4, xp = lane & 15;
+    // Counted waits of the LAST trip: there is no next trip to fetch tokens for, so its second half issues 8 P and no T per stage; the
+    // barrier of its stage u sees 17, 19, 21, 21, 20, 18, 16, 16 younger operations.
     const unsigned dlu = __builtin_amdgcn_readfirstlane(dl);      // (wave-uniform by construction; said again for the "s" operands below)
-    unsigned xoff[8];                              // byte offset of (row 4 r4 + xr, piece xp of quarter 0) in xhat / dres / dx
-#pragma unroll
-    for (int r4 = 0; r4 < 8; ++r4) xoff[r4] = (unsigned)min(mw + 4 * r4 + xr, M - 1) * (RN_N * 2) + xp * 16;
-#define RN_XLD(n_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xr_[n_]) : "v"(xoff[(n_) & 7]), "s"(xhat), "n"(((n_) >> 3) * 256) : "memory")
-#define RN_TRIP(LAST_, XPF_)                                                                                             \
+#define RN_XLD(n_) ((void)0)
+#define RN_TRIP(LAST_, XPF_, DP_)                                                                                           \
     {                                                                                                                \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                              \
             const int q = q0 + u;                                                                                    \
@@ -159,7 +167,13 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
                 /* slot k: k-step (k >> 4) of the stage, column tile k & 15 */                                       \
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[k & 15]) : "v"(fb[k & 7]), "v"(tok[(2 * u + (k >> 4)) & 15])); \
                 if ((k & 3) == 3) {                                                                                  \
-                    if (k < 24) rn_glds(n3 + ((k >> 2) + 2) * 4096, wvo, dlu, ((u + 3) & 3) * 8 + (k >> 2) + 2);                     \
+                    /* LAST trip, from slot 27 of stage 4 on: the stream has no stage q + 4 / q + 3 left, and the ring slot such a   \
+                       piece would go to is never read again (it used to be a re-read of the last stage, so that the wait counts     \
+                       stay constant).  DP_: piece n = 0..25 of the EPILOGUE's input goes there instead -- same position in the     \
+                       in-order counter, so no counted wait changes -- into the wave's KiB of ring slot n >> 3, piece n & 7 */        \
+                    if (LAST_ && DP_ && k < 24 && u >= 5) RN_DPIECE(8 * (u - 5) + (k >> 2) + 2, ((u + 3) & 3) * 8 + (k >> 2) + 2);   \
+                    else if (LAST_ && DP_ && k >= 24 && u >= 4) RN_DPIECE(8 * (u - 4) + (k >> 2) - 6, ((u + 4) & 3) * 8 + (k >> 2) - 6); \
+                    else if (k < 24) rn_glds(n3 + ((k >> 2) + 2) * 4096, wvo, dlu, ((u + 3) & 3) * 8 + (k >> 2) + 2);                \
                     else rn_glds(n4 + ((k >> 2) - 6) * 4096, wvo, dlu, ((u + 4) & 3) * 8 + (k >> 2) - 6);                             \
                 }                                                                                                    \
                 /* (no token loads in the second half of the LAST trip: a register an asm load writes but nobody reads is dead to the   \
@@ -174,40 +188,46 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     }
     int q0 = 0;
     if (!(MBX_RN_DBG & 2)) {
-        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, true)
-        RN_TRIP(true, true)
+        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false, false)
+        RN_TRIP(true, false, true)
     }
     RN_TS(2);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the re-read tail stages, the over-read tokens and xhat have landed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the tail of the stream, the over-read tokens and xhat have landed
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring: 32 KiB of it per wave are buffers now
     RN_TS(3);
     if (MBX_RN_DBG & 1) return;
 #pragma unroll
     for (int t = 0; t < 16; ++t) MFMA_PAD_A(acc[t]);
-#pragma unroll
-    for (int n = 0; n < 32; n += 8)                                  // (data dependence on the wait above for the registers the asm loads wrote)
-        asm volatile("" : "+v"(xr_[n]), "+v"(xr_[n + 1]), "+v"(xr_[n + 2]), "+v"(xr_[n + 3]), "+v"(xr_[n + 4]), "+v"(xr_[n + 5]), "+v"(xr_[n + 6]), "+v"(xr_[n + 7]));
-
-    // ---- epilogue.  The wave's 32 KiB of the ring take its 32 x 512 slice of xhat (four quarters of 128 columns, written from the
-    // registers the last trip filled); a fifth 8-KiB buffer per wave behind the ring (the kernel uses all 160 KiB of LDS) takes one
-    // quarter of dres at a time, by LDS-DMA: no registers, and nothing the compiler could move (an earlier version fetched dres with
-    // asm loads into registers: under this epilogue's register pressure the compiler gave all eight loads of a quarter ONE destination
-    // and copied it out before the data had landed -- an asm output is "defined" where the statement stands).  In a buffer row r takes
-    // 256 bytes and its 16-byte piece p sits at slot p ^ (r & 15); a lane reads its accumulator positions (row i, columns
-    // 32 ntl + 8 qq + 4 g + e of the quarter) as 8-byte halves of pieces.
+    // ---- epilogue.  xhat is on chip: piece n = 8 j + r4 in the wave's KiB of (ring slot n >> 3, piece n & 7) for n < 26 and in KiB r4 of
+    // the wave's fifth buffer for n >= 26; inside a KiB row r takes 256 bytes, its 16-byte piece p sits at slot p ^ (r & 15), and a lane
+    // reads its accumulator positions (row i, columns 32 ntl + 8 qq + 4 g + e of the quarter) as 8-byte halves of pieces.  The wave's other
+    // 8 KiB -- ring slot 3, pieces 2..7, and KiBs 0, 1 of the fifth buffer -- take one quarter of dres at a time, by LDS-DMA, in the same
+    // image (an earlier version fetched dres with asm loads into registers: under this epilogue's register pressure the compiler gave
+    // all eight loads of a quarter ONE destination and copied it out before the data had landed -- an asm output is "defined" where the
+    // statement stands).
     //   pass 1: the two row means from the accumulators and xhat;
     //   pass 2, per quarter: dx written over the xhat it was made from, read back row-major, stored as whole 256-byte row segments;
     //   the next quarter of dres is requested as soon as this one has been read, and lands while this one's dx is read out and stored.
-    // (lane-derived values are re-derived from an opaque copy of the thread index: otherwise they are carried through the loop in registers
-    // the last trip needs)
+    // (Measured and dropped in round 6, profiles/r06_rows_n_ablation.txt: dres requested during the loop as well / a whole quarter of
+    // arithmetic ahead -- the epilogue is not waiting for its loads but for its own LDS round trips and ~2700 VALU instructions at one
+    // wave per SIMD.)
+    // (lane-derived values are re-derived from an opaque copy of the thread index: otherwise they are carried through the loop)
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63, i_e = lane_e & 31, g_e = lane_e >> 5, xr_e = lane_e >> 4, xp_e = lane_e & 15;
-    char* const eb = ring + wave * 32768;
+    char* const rw = ring + wave * 1024;                              // the wave's KiB of (ring slot s, piece p): rw + s * 32768 + p * 4096
     char* const bd = ring + RN_RING + wave * 8192;
+    const unsigned rwl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024);
     const unsigned bdl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const lds_void_t*)ring + RN_RING + wave * 8192);
-    // DMA instruction r4 fills rows 4 r4 .. 4 r4 + 3 of the buffer: lane (xr, xp) lands in slot xp of row rl = 4 r4 + xr, so it fetches
-    // piece xp ^ (rl & 15) of that row
+    // KiB (j, r4) of xhat / KiB c of the dres image, for compile-time indices: generic pointer, and LDS address for the DMA
+#define RN_XCH(j_, r4_) (8 * (j_) + (r4_) < 26 ? rw + (j_) * 32768 + (r4_) * 4096 : bd + (r4_) * 1024)
+#define RN_STG_L(c_) ((c_) < 2 ? bdl + (c_) * 1024 : rwl + 3 * 32768 + (c_) * 4096)
+    // ... and for the lane's own row i (KiB i >> 2, row i & 3 of it) in the accumulator layout
+    const int ck = i_e >> 2, inr = (i_e & 3) * 256 + 8 * g_e, sx = (i_e & 15) << 4;
+    char* const xc_i = rw + ck * 4096 + inr;                          // + j * 32768 for quarters 0..2
+    char* const xc3_i = (ck < 2 ? rw + 3 * 32768 + ck * 4096 : bd + ck * 1024) + inr;
+    const char* const dx_ = (ck < 2 ? bd + ck * 1024 : rw + 3 * 32768 + ck * 4096) + inr;
+    // DMA instruction r4 of a quarter of dres: the same rows and pieces as of xhat
     unsigned doff[8];
 #pragma unroll
     for (int r4 = 0; r4 < 8; ++r4) {
@@ -215,23 +235,15 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
         doff[r4] = (unsigned)min(mw + rl, M - 1) * (RN_N * 2) + ((xp_e ^ (rl & 15)) << 4);
     }
 #define RN_DDMA(j_) _Pragma("unroll") for (int r4_ = 0; r4_ < 8; ++r4_)                                              \
-        glds16_s(reinterpret_cast<const char*>(dres_t) + (j_) * 256, doff[r4_], bdl + r4_ * 1024)
+        glds16_s(reinterpret_cast<const char*>(dres_t) + (j_) * 256, doff[r4_], RN_STG_L(r4_))
     RN_DDMA(0);
-#pragma unroll
-    for (int n = 0; n < 32; ++n) {                 // quarter n >> 3, rows 4 (n & 7) + xr
-        const int rl = 4 * (n & 7) + xr_e;
-        *reinterpret_cast<u32x4_t*>(eb + (n >> 3) * 8192 + rl * 256 + ((xp_e ^ (rl & 15)) << 4)) = xr_[n];
-    }
     const float rs = rstd[min(mw + i_e, M - 1)];
     float c1 = 0.f, c2 = 0.f;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the rows a lane reads were written by other lanes of THIS wave: in order)
     RN_TS(4);
-    // (round 6: the four reads of tile nt + 1 are issued in front of the arithmetic of tile nt.  One wave per SIMD means nothing else
-    // covers a ds_read -> use pair: as written in round 5 every tile of both passes waited out its own LDS round trip, 228 s_waitcnt in
-    // 2700 VALU instructions -- profiles/r06_rows_n_ablation.txt)
-    const char* const ex = eb + i_e * 256 + 8 * g_e;
-    const int sx = (i_e & 15) << 4;
-#define RN_XRD(nt_, qq_) (*reinterpret_cast<const uint2*>(ex + ((nt_) >> 2) * 8192 + (((((nt_) & 3) * 4 + (qq_)) << 4) ^ sx)))
+    // (the four reads of tile nt + 1 are issued in front of the arithmetic of tile nt.  One wave per SIMD means nothing else covers a
+    // ds_read -> use pair: as written in round 5 every tile of both passes waited out its own LDS round trip, 228 s_waitcnt in 2700 VALU
+    // instructions -- profiles/r06_rows_n_ablation.txt)
+#define RN_XRD(nt_, qq_) (*reinterpret_cast<const uint2*>(((nt_) < 12 ? xc_i + ((nt_) >> 2) * 32768 : xc3_i) + (((((nt_) & 3) * 4 + (qq_)) << 4) ^ sx)))
     uint2 xq[2][4];
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) xq[0][qq] = RN_XRD(0, qq);
@@ -260,7 +272,6 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     for (int j = 0; j < 4; ++j) {
         // vector memory operations younger than the DMA of quarter j: the stores of quarter j - 1 (8)
         if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        const char* const dx_ = bd + i_e * 256 + 8 * g_e;
 #define RN_DRD(ntl_, qq_) (*reinterpret_cast<const uint2*>(dx_ + ((((ntl_) * 4 + (qq_)) << 4) ^ sx)))
         uint2 xp2[2][4], dp2[2][4];
 #pragma unroll
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             const f32x16_t t = acc[4 * j + ntl];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                uint2* const p = reinterpret_cast<uint2*>(eb + j * 8192 + i_e * 256 + 8 * g_e + (((ntl * 4 + qq) << 4) ^ sx));
+                uint2* const p = reinterpret_cast<uint2*>((j < 3 ? xc_i + j * 32768 : xc3_i) + (((ntl * 4 + qq) << 4) ^ sx));
                 const uint2 xv = xp2[ntl & 1][qq];
                 const uint2 dv = dp2[ntl & 1][qq];
                 const float d0 = __uint_as_float(dv.x << 16), d1 = __uint_as_float(dv.x & 0xffff0000u);
@@ -287,12 +298,12 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // dres has been read (the buffer is free), dx is in place
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // dres has been read (its image is free), dx is in place
         if (j == 0) { RN_DDMA(1); } else if (j == 1) { RN_DDMA(2); } else if (j == 2) { RN_DDMA(3); }
 #pragma unroll
         for (int r4 = 0; r4 < 8; ++r4) {
             const int rl = 4 * r4 + xr_e;
-            const uint4 v = *reinterpret_cast<const uint4*>(eb + j * 8192 + r4 * 1024 + lane_e * 16);
+            const uint4 v = *reinterpret_cast<const uint4*>(RN_XCH(j, r4) + lane_e * 16);
             // rows past M were computed from row M - 1's inputs (every load is clamped) and are stored onto row M - 1: identical bytes,
             // and every wave issues the same number of vector memory instructions -- the counted waits above depend on it
             *reinterpret_cast<uint4*>(dx_t + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp_e ^ (rl & 15)) << 3)) = v;
@@ -372,12 +383,12 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     u32x4_t fb[8];
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
-#undef RN_XLD
-#define RN_XLD(n_) ((void)0)
+#undef RN_DPIECE
+#define RN_DPIECE(n_, sp_) ((void)0)
     int q0 = 0;
     if (!(MBX_RN_DBG & 2)) {
-        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
-        RN_TRIP(true, false)
+        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false, false)
+        RN_TRIP(true, false, false)
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bq0), "+v"(bq1) : : "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
