@@ -383,12 +383,19 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     u32x4_t fb[8];
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
+    // (round 6) the 26 slots of the last trip in which the stream has nothing left to fetch request the first 26 KiB of the epilogue's
+    // input: KiB m = 16 b + d = rows 2 d, 2 d + 1 of quarter b of resid (fp32, 128 columns = 512 bytes per row; lane l fetches the piece
+    // that belongs in slot l & 31 of row 2 d + (l >> 5): piece (l & 31) ^ row), into the wave's KiB of ring slot m >> 3, piece m & 7 --
+    // all of quarter 0 and ten sixteenths of quarter 1.  (They used to re-read the last stage: a fifth of the stream's requests at K = 512.)
+    unsigned doff[16];                             // byte offset of (row 2 d + g, piece i ^ row of quarter 0) in resid and y
+#pragma unroll
+    for (int d = 0; d < 16; ++d) doff[d] = (unsigned)min(mw + 2 * d + g, M - 1) * (RN_N * 4) + ((i ^ (2 * d + g)) << 4);
 #undef RN_DPIECE
-#define RN_DPIECE(n_, sp_) ((void)0)
+#define RN_DPIECE(n_, sp_) rn_glds(reinterpret_cast<const char*>(resid) + ((n_) >> 4) * 512, doff[(n_) & 15], dlu, sp_)
     int q0 = 0;
     if (!(MBX_RN_DBG & 2)) {
         for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false, false)
-        RN_TRIP(true, false, false)
+        RN_TRIP(true, false, true)
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bq0), "+v"(bq1) : : "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
@@ -399,36 +406,52 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63, i_e = lane_e & 31, g_e = lane_e >> 5, xr_e = lane_e >> 4, xp_e = lane_e & 15;
-    char* const eb = ring + wave * 32768;
+    char* const rw = ring + wave * 1024;                              // the wave's KiB of (ring slot s, piece p): rw + s * 32768 + p * 4096
     char* const bx = ring + RN_RING + wave * 8192;
-    const unsigned ebl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 32768);
-    // DMA / read-out instruction d moves rows 2 d, 2 d + 1 of a quarter: lane l = slot l & 31 of row rl = 2 d + (l >> 5), i.e. piece
-    // (l & 31) ^ rl of that row; the same byte offset addresses resid and y
-    unsigned doff[16];
+    const unsigned rwl = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024);
+    // Two images of one quarter of resid each (double-buffered against the stores): KiB d (rows 2 d, 2 d + 1: a row takes 512 bytes, its
+    // 16-byte piece p sits at slot p ^ row) of image b is the wave's KiB m = 16 b + d of the ring, i.e. of (ring slot m >> 3, piece m & 7).
+    // DMA / read-out instruction d moves that KiB; the same byte offset (doff) addresses resid and y.
+#define RN_RCH(b_, d_) (rw + ((16 * (b_) + (d_)) >> 3) * 32768 + ((16 * (b_) + (d_)) & 7) * 4096)
+#define RN_RCH_L(b_, d_) (rwl + ((16 * (b_) + (d_)) >> 3) * 32768 + ((16 * (b_) + (d_)) & 7) * 4096)
+#define RN_RDMA(j_, b_, d0_) _Pragma("unroll") for (int d_ = (d0_); d_ < 16; ++d_)                                   \
+        glds16_s(reinterpret_cast<const char*>(resid) + (j_) * 512, doff_e[d_], RN_RCH_L(b_, d_))
+    unsigned doff_e[16];
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
         const int rl = 2 * d + g_e;
-        doff[d] = (unsigned)min(mw + rl, M - 1) * (RN_N * 4) + ((i_e ^ rl) << 4);
+        doff_e[d] = (unsigned)min(mw + rl, M - 1) * (RN_N * 4) + ((i_e ^ rl) << 4);
     }
-#define RN_RDMA(j_, b_) _Pragma("unroll") for (int d_ = 0; d_ < 16; ++d_)                                             \
-        glds16_s(reinterpret_cast<const char*>(resid) + (j_) * 512, doff[d_], ebl + (b_) * 16384 + d_ * 1024)
-    RN_RDMA(0, 0);
-    RN_RDMA(1, 1);
+    RN_RDMA(1, 1, 10);                                                // what the last trip could not fit of quarter 1: KiBs 26..31 of the ring
     *reinterpret_cast<u32x4_t*>(bx + lane_e * 32) = bq0;              // bias[8 lane .. 8 lane + 7]: read below by every lane that holds those columns
     *reinterpret_cast<u32x4_t*>(bx + lane_e * 32 + 16) = bq1;
+    // the lane's own row i in the accumulator layout: KiB i >> 1 of an image, row i & 1 of it
+    char* const rb_i = rw + (i_e >> 4) * 32768 + ((i_e >> 1) & 7) * 4096 + (i_e & 1) * 512;      // + b * 65536
+    const int sx = i_e << 4;
     float s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        // vector memory operations younger than the DMA of quarter j: [the stores of quarter j - 1 (16)] + the DMA of quarter j + 1 (16)
-        if (j == 0 || j == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        char* const buf = eb + (j & 1) * 16384;
+        // vector memory operations younger than the last DMA of quarter j, in issue order  R1' (6) | S0 (16) R2 (16) | S1 R3 | S2 | S3:
+        // quarter 0 landed with the loop's drain
+        if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else if (j == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        char* const rbj = rb_i + (j & 1) * 65536;
+#define RN_RRD(ntl_, qq_) (*reinterpret_cast<const float4*>(rbj + (((8 * (ntl_) + 2 * (qq_) + g_e) << 4) ^ sx)))
+#define RN_BRD(ntl_, qq_) (*reinterpret_cast<const float4*>(bx + (32 * (4 * j + (ntl_)) + 8 * (qq_) + 4 * g_e) * 4))
+        // (the reads of tile ntl + 1 are issued in front of the arithmetic of tile ntl: one wave per SIMD, nothing else covers the round trip)
+        float4 rq[2][4], bq[2][4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) { rq[0][qq] = RN_RRD(0, qq); bq[0][qq] = RN_BRD(0, qq); }
 #pragma unroll
         for (int ntl = 0; ntl < 4; ++ntl) {
+            if (ntl + 1 < 4) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) { rq[(ntl + 1) & 1][qq] = RN_RRD(ntl + 1, qq); bq[(ntl + 1) & 1][qq] = RN_BRD(ntl + 1, qq); }
+            }
             f32x16_t t = acc[4 * j + ntl];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                float4* const p = reinterpret_cast<float4*>(buf + i_e * 512 + (((8 * ntl + 2 * qq + g_e) ^ i_e) << 4));
-                const float4 r = *p, b = *reinterpret_cast<const float4*>(bx + (32 * (4 * j + ntl) + 8 * qq + 4 * g_e) * 4);
+                float4* const p = reinterpret_cast<float4*>(rbj + (((8 * ntl + 2 * qq + g_e) << 4) ^ sx));
+                const float4 r = rq[ntl & 1][qq], b = bq[ntl & 1][qq];
                 t[4 * qq] += r.x + b.x; t[4 * qq + 1] += r.y + b.y; t[4 * qq + 2] += r.z + b.z; t[4 * qq + 3] += r.w + b.w;
                 *p = make_float4(t[4 * qq], t[4 * qq + 1], t[4 * qq + 2], t[4 * qq + 3]);      // y over the resid it was made from
                 s1 += (t[4 * qq] + t[4 * qq + 1]) + (t[4 * qq + 2] + t[4 * qq + 3]);
@@ -439,13 +462,13 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
-            const float4 v = *reinterpret_cast<const float4*>(buf + d * 1024 + lane_e * 16);
+            const float4 v = *reinterpret_cast<const float4*>(RN_RCH(j & 1, d) + lane_e * 16);
             // (rows past M carry row M - 1's values -- every load is clamped -- and are stored onto row M - 1: identical bytes, and every
             // wave issues the same number of vector memory instructions, which the counted waits depend on)
-            *reinterpret_cast<float4*>(reinterpret_cast<char*>(y) + doff[d] + j * 512) = v;
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(y) + doff_e[d] + j * 512) = v;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the buffer has been read out
-        if (j == 0) { RN_RDMA(2, 0); } else if (j == 1) { RN_RDMA(3, 1); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the image has been read out
+        if (j == 0) { RN_RDMA(2, 0, 0); } else if (j == 1) { RN_RDMA(3, 1, 0); }
     }
     // LayerNorm statistics of the 512 values of row i (lanes i and i + 32 hold its halves): two passes, as ln_fwd_row
     const float mu = wave_halves<WaveAdd>(s1) * (1.0f / (float)RN_N);
