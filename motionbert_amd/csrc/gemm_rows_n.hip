@@ -481,27 +481,33 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
         __builtin_amdgcn_sched_barrier(0);
     }
     const float rs = 1.0f / sqrtf(wave_halves<WaveAdd>(s2) * (1.0f / (float)RN_N) + eps);
+    // xhat leaves through the wave's 32 KiB of the ring, which y has left (round 6; round 5 sent the four quarters through the 8-KiB fifth
+    // buffer one after the other, two LDS round trips per quarter): quarter j, rows 4 r4 .. 4 r4 + 3 (256 bytes per row, piece p of row r at
+    // slot p ^ (r & 15)) in the wave's KiB of (ring slot j, piece r4); written in the accumulator layout, read back row-major, stored as
+    // whole 256-byte row segments -- all writes, one wait, all reads
+    char* const xw_i = rw + (i_e >> 2) * 4096 + (i_e & 3) * 256 + 8 * g_e;
+    const int sxh = (i_e & 15) << 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int ntl = 0; ntl < 4; ++ntl) {
             const f32x16_t t = acc[4 * j + ntl];
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int off = i_e * 256 + (((ntl * 4 + qq) ^ (i_e & 15)) << 4) + 8 * g_e;
-                *reinterpret_cast<uint2*>(bx + off) = make_uint2(pack_bf2((t[4 * qq] - mu) * rs, (t[4 * qq + 1] - mu) * rs),
-                                                                 pack_bf2((t[4 * qq + 2] - mu) * rs, (t[4 * qq + 3] - mu) * rs));
-            }
+            for (int qq = 0; qq < 4; ++qq)
+                *reinterpret_cast<uint2*>(xw_i + j * 32768 + (((ntl * 4 + qq) << 4) ^ sxh)) =
+                    make_uint2(pack_bf2((t[4 * qq] - mu) * rs, (t[4 * qq + 1] - mu) * rs), pack_bf2((t[4 * qq + 2] - mu) * rs, (t[4 * qq + 3] - mu) * rs));
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int r4 = 0; r4 < 8; ++r4) {
             const int rl = 4 * r4 + xr_e;
-            const uint4 v = *reinterpret_cast<const uint4*>(bx + r4 * 1024 + lane_e * 16);
+            const uint4 v = *reinterpret_cast<const uint4*>(rw + j * 32768 + r4 * 4096 + lane_e * 16);
             *reinterpret_cast<uint4*>(xhat_o + (size_t)min(mw + rl, M - 1) * RN_N + j * 128 + ((xp_e ^ (rl & 15)) << 3)) = v;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (g_e == 0 && mw + i_e < M) {
         mean_o[mw + i_e] = mu;
