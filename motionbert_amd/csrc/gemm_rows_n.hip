@@ -26,6 +26,13 @@
 // (q: 6 P, T); everything older -- in particular the tokens of stage q + 1, issued in stage q - 3 -- has landed with it, so the token
 // registers need no wait of their own.  The preamble issues the first eight tokens BEFORE the ring instead of interleaved: the first two
 // stages of a trip wait for 17 / 19 instead of 21 (a slightly stronger wait on later trips, no branch).
+// Round 6 -- the tail of the stream.  From slot 27 of stage 4 of the LAST trip on there is no stage q + 4 / q + 3 left to request.  Round 5
+// re-read the last stage in those 26 slots (so that the counts stay constant); now they request the first 26 KiB per wave of the
+// EPILOGUE's input -- xhat here, resid in the kernel further down -- straight into the ring slots the loop has left for good (slot s is
+// free once the barrier of the stage that read it last has been passed, exactly as for a refill).  Same position in the in-order counter,
+// so no counted wait changed.  It also took an in-order hazard out of the loop: round 5 fetched xhat with 32 register loads spread over
+// the last trip, first-touch HBM loads that sat in the counter in FRONT of the weight pieces every barrier waits for -- the last trip
+// ran 4 us slower than the others (profiles/r06_rn_trace.txt).
 #include "mbx_common.h"
 #include "lds_stream.h"
 
@@ -143,8 +150,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     // Counted waits of the LAST trip: there is no next trip to fetch tokens for, so its second half issues 8 P and no T per stage; the
     // barrier of its stage u sees 17, 19, 21, 21, 20, 18, 16, 16 younger operations.
     const unsigned dlu = __builtin_amdgcn_readfirstlane(dl);      // (wave-uniform by construction; said again for the "s" operands below)
-#define RN_XLD(n_) ((void)0)
-#define RN_TRIP(LAST_, XPF_, DP_)                                                                                           \
+#define RN_TRIP(LAST_, DP_)                                                                                                 \
     {                                                                                                                \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                              \
             const int q = q0 + u;                                                                                    \
@@ -154,9 +160,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             const char* const n4 = wpk + (size_t)min(q + 4, nstages - 1) * RN_STAGE;                                 \
             _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                         \
                 if (k == 32 - PF) {                                                                                  \
-                    if (LAST_ && XPF_) { if (u == 0) rn_vmwait<23>(); else if (u == 1) rn_vmwait<27>(); else if (u < 4) rn_vmwait<31>(); \
-                                 else if (u == 4) rn_vmwait<30>(); else if (u == 5) rn_vmwait<28>(); else rn_vmwait<26>(); }      \
-                    else if (LAST_) { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else if (u < 4) rn_vmwait<21>(); \
+                    if (LAST_) { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else if (u < 4) rn_vmwait<21>(); \
                                  else if (u == 4) rn_vmwait<20>(); else if (u == 5) rn_vmwait<18>(); else rn_vmwait<16>(); }      \
                     else { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else rn_vmwait<21>(); }    \
                     __builtin_amdgcn_sched_barrier(0);                                                               \
@@ -180,7 +184,6 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
                    compiler, which hands it to something else -- and the load lands in it later) */                                     \
                 if (k == 25) { if (u < 4) RN_TOK(tok[(2 * (u + 4)) & 15], 32 * (2 * (u + 4))); else if (!LAST_) RN_TOKN(tok[(2 * (u + 4)) & 15], 32 * (2 * (u - 4))); } \
                 if (k == 29) { if (u < 4) RN_TOK(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u + 4) + 1)); else if (!LAST_) RN_TOKN(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u - 4) + 1)); } \
-                if (LAST_ && XPF_ && k >= 24 && !(k & 1)) RN_XLD(4 * u + ((k - 24) >> 1));                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                                   \
             }                                                                                                        \
         }                                                                                                            \
@@ -188,8 +191,8 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     }
     int q0 = 0;
     if (!(MBX_RN_DBG & 2)) {
-        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false, false)
-        RN_TRIP(true, false, true)
+        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
+        RN_TRIP(true, true)
     }
     RN_TS(2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the tail of the stream, the over-read tokens and xhat have landed
@@ -394,8 +397,8 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
 #define RN_DPIECE(n_, sp_) rn_glds(reinterpret_cast<const char*>(resid) + ((n_) >> 4) * 512, doff[(n_) & 15], dlu, sp_)
     int q0 = 0;
     if (!(MBX_RN_DBG & 2)) {
-        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false, false)
-        RN_TRIP(true, false, true)
+        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
+        RN_TRIP(true, true)
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bq0), "+v"(bq1) : : "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring

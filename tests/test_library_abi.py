@@ -70,11 +70,13 @@ def test_device_code_policy(lib, tmp_path):
 
 
 def test_asm_prefetch_registers_are_left_alone(lib, tmp_path):
-    """The N-resident LayerNorm-backward kernel (csrc/gemm_rows_n.hip) requests part of its epilogue's input with inline-asm loads inside
-    the last trip of the loop.  To the compiler an asm output is valid where the statement stands: if register pressure made it copy
-    or reuse one of those registers before the kernel's own `s_waitcnt vmcnt(0)`, the copy would hold stale bits (round 5 found both
-    failure modes in the epilogue of an earlier version).  Checked on the disassembly: its 32 loads have 128 distinct
-    destination registers, and no instruction between a load and that wait names a register it has already written."""
+    """The N-resident row-owner kernels (csrc/gemm_rows_n.hip) fetch their token fragments with inline-asm loads four stages ahead of the
+    MFMAs that consume them, ordered by the kernels' own counted waits.  To the compiler an asm output is valid where the statement
+    stands: if register pressure made it copy, spill or reuse one of those registers before the data has landed, the copy would hold
+    stale bits (round 5 found both failure modes in the epilogue of an earlier version; round 6 moved the last register prefetch of an
+    epilogue input -- xhat -- to LDS-DMA, which has no register side).  Checked on the disassembly of both kernels: the first instruction
+    that names a destination register of a token load after the load is an MFMA (never a copy, a spill or a VALU operation), and no
+    load of this form exists besides the token loads (8 in the preamble + 16 per trip, two trips in the code)."""
     import re
     import shutil
     import subprocess
@@ -88,32 +90,26 @@ def test_asm_prefetch_registers_are_left_alone(lib, tmp_path):
     seen = 0
     for o in [p for p in tmp_path.iterdir() if 'amdgcn' in p.name]:
         asm = subprocess.run([objdump, '-d', '--mcpu=gfx950', str(o)], check=True, capture_output=True, text=True).stdout
-        for kern in ('rows_n_lnbwd_kernel',):
+        for kern in ('rows_n_lnbwd_kernel', 'rows_n_resid_ln_kernel'):
             m = re.search(r'^[0-9a-f]+ <_Z\d+' + kern + r'[^>]*>:\n(.*?)s_endpgm', asm, re.S | re.M)
             if not m:
                 continue
             seen += 1
-            lines = m.group(1).split('\n')
-            loads = []      # (line, first, last) of global_load_dwordx4 vdst, voff, s[..]  (the SGPR-base form only these prefetches use)
+            lines = [l.split('//')[0] for l in m.group(1).split('\n')]
+            loads = []      # (line, registers) of global_load_dwordx4 vdst, voff, s[..]: the SGPR-base form only the token loads use
             for n, l in enumerate(lines):
                 mm = re.search(r'global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\]', l)
                 if mm:
-                    loads.append((n, int(mm.group(1)), int(mm.group(2))))
+                    loads.append((n, set(range(int(mm.group(1)), int(mm.group(2)) + 1))))
+            # 8 in the preamble, 16 in the ordinary trip, 8 in the peeled last trip (its second half has no next trip to fetch for)
             assert len(loads) == 32, (kern, len(loads))
-            regs = [r for _, a, b in loads for r in range(a, b + 1)]
-            assert len(set(regs)) == 128, f'{kern}: prefetch loads share destination registers'
-            wait = next(n for n, l in enumerate(lines) if n > loads[-1][0] and 's_waitcnt vmcnt(0)' in l)
-            written = set()
-            nxt = 0
-            for n in range(loads[0][0], wait):
-                if nxt < len(loads) and loads[nxt][0] == n:
-                    written.update(range(loads[nxt][1], loads[nxt][2] + 1))
-                    nxt += 1
-                    continue
-                l = lines[n].split('//')[0]
-                used = set()
-                for mm in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', l):
-                    used.update([int(mm.group(3))] if mm.group(3) else range(int(mm.group(1)), int(mm.group(2)) + 1))
-                assert not (used & written), f'{kern}: "{l.strip()}" touches a prefetch register before the wait'
-    assert seen == 1, 'row-owner kernel not found in the device code'
+            for n, regs in loads:
+                for k in range(n + 1, len(lines)):
+                    used = set()
+                    for mm in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', lines[k]):
+                        used.update([int(mm.group(3))] if mm.group(3) else range(int(mm.group(1)), int(mm.group(2)) + 1))
+                    if used & regs:
+                        assert 'v_mfma' in lines[k], f'{kern}: "{lines[k].strip()}" touches the registers of the token load in line {n} before an MFMA read them'
+                        break
+    assert seen == 2, 'row-owner kernels not found in the device code'
 
