@@ -195,12 +195,15 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
         RN_TRIP(true, true)
     }
     RN_TS(2);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the tail of the stream, the over-read tokens and xhat have landed
+    // (no drain of the vector memory counter here: the pieces of xhat requested in the last stages are first-touch loads that are still
+    // on their way; pass 1 below waits for them quarter by quarter, by count)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring: 32 KiB of it per wave are buffers now
     RN_TS(3);
     if (MBX_RN_DBG & 1) return;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) MFMA_PAD_A(acc[t]);
+    // ONE pad for all sixteen tiles (the wait states between the last MFMA and the first non-MFMA reader of its result)
+    asm volatile("s_nop 15" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]),
+                 "+a"(acc[8]), "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]), "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15]));
     // ---- epilogue.  xhat is on chip: piece n = 8 j + r4 in the wave's KiB of (ring slot n >> 3, piece n & 7) for n < 26 and in KiB r4 of
     // the wave's fifth buffer for n >= 26; inside a KiB row r takes 256 bytes, its 16-byte piece p sits at slot p ^ (r & 15), and a lane
     // reads its accumulator positions (row i, columns 32 ntl + 8 qq + 4 g + e of the quarter) as 8-byte halves of pieces.  The wave's other
@@ -248,10 +251,15 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     // instructions -- profiles/r06_rows_n_ablation.txt)
 #define RN_XRD(nt_, qq_) (*reinterpret_cast<const uint2*>(((nt_) < 12 ? xc_i + ((nt_) >> 2) * 32768 : xc3_i) + (((((nt_) & 3) * 4 + (qq_)) << 4) ^ sx)))
     uint2 xq[2][4];
+    // Counted waits for xhat, in issue order  ... | n0 .. n7 | n8 .. n15 | n16 .. n23 | n24 n25 | D0 (8) [| rstd]: quarter j of xhat (pieces
+    // 8 j .. 8 j + 7; 26..31 are the oldest operations of the kernel) has landed when at most 26 / 18 / 10 / 8 younger operations are
+    // in flight.  (The compiler's load of rstd sits behind D0 in program order; if it is there the waits are one stronger than needed.)
+    rn_vmwait<26>();
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) xq[0][qq] = RN_XRD(0, qq);
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) {
+        if (nt == 3) rn_vmwait<18>(); else if (nt == 7) rn_vmwait<10>(); else if (nt == 11) rn_vmwait<8>();
         if (nt + 1 < 16) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) xq[(nt + 1) & 1][qq] = RN_XRD(nt + 1, qq);
@@ -400,7 +408,9 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
         for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
         RN_TRIP(true, true)
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bq0), "+v"(bq1) : : "memory");
+    // (no drain of the vector memory counter: the KiBs of resid requested in the last stages are still on their way; counted wait below.
+    // The bias registers -- the oldest loads of the kernel, landed since the first counted wait of the loop -- take their data dependence here)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq0), "+v"(bq1) : : "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
     if (MBX_RN_DBG & 1) return;
 #pragma unroll
@@ -426,6 +436,8 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
         doff_e[d] = (unsigned)min(mw + rl, M - 1) * (RN_N * 4) + ((i_e ^ rl) << 4);
     }
     RN_RDMA(1, 1, 10);                                                // what the last trip could not fit of quarter 1: KiBs 26..31 of the ring
+    // quarter 0 (KiBs 0..15 of the last trip's 26) has landed when at most the 10 KiBs behind it and these 6 are in flight
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     *reinterpret_cast<u32x4_t*>(bx + lane_e * 32) = bq0;              // bias[8 lane .. 8 lane + 7]: read below by every lane that holds those columns
     *reinterpret_cast<u32x4_t*>(bx + lane_e * 32 + 16) = bq1;
     // the lane's own row i in the accumulator layout: KiB i >> 1 of an image, row i & 1 of it
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // vector memory operations younger than the last DMA of quarter j, in issue order  R1' (6) | S0 (16) R2 (16) | S1 R3 | S2 | S3:
-        // quarter 0 landed with the loop's drain
+        // quarter 0: waited for above
         if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else if (j == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         char* const rbj = rb_i + (j & 1) * 65536;
 #define RN_RRD(ntl_, qq_) (*reinterpret_cast<const float4*>(rbj + (((8 * (ntl_) + 2 * (qq_) + g_e) << 4) ^ sx)))
