@@ -80,6 +80,9 @@ def pose_loss(pred, gt):
 # the NT GEMM entries of the C ABI (same kernels, different epilogues): mbx_gemm_nt, and with LayerNorm folding the GELU' epilogue
 # that also emits row dots and the dX GEMM whose epilogue is the LayerNorm backward
 NT_FAMILY = ('gemm_nt', 'gemm_nt_dgelu_stats', 'gemm_nt_lnbwd', 'gemm_nt_gelu_d', 'gemm_nt_mul')
+# ... and the two N-resident row-owner entries (round 5), which took over the N = 512 products with a row-wise epilogue: with them the
+# aggregate below is EVERY A . W^T GEMM launch of a step (the figure used to cover the tile kernels only)
+NT_ALL = NT_FAMILY + ('rows_lnbwd_t', 'rows_resid_ln')
 
 
 class TimedOps:
@@ -244,7 +247,7 @@ def _port_calibration():
         return None
 
 
-PMC_TABLE = next((p for p in (os.path.join(ROOT, 'profiles', f'r0{r}_pmc_bench.txt') for r in (5, 4, 3, 2)) if os.path.exists(p)),
+PMC_TABLE = next((p for p in (os.path.join(ROOT, 'profiles', f'r0{r}_pmc_bench.txt') for r in (6, 5, 4, 3, 2)) if os.path.exists(p)),
                  os.path.join(ROOT, 'profiles', 'r03_pmc_bench.txt'))
 HBM_PEAK_TBS, HBM_ACHIEVABLE_TBS = 8.0, 6.3      # MI355X_MICROARCH.md: spec / measured float4 copy
 
@@ -259,7 +262,7 @@ def pmc_traffic_bytes(B, T, precision):
         return None
     tot, n = 0.0, 0
     for line in open(PMC_TABLE):
-        if 'gemm_nt' not in line or line.startswith('#'):
+        if ('gemm_nt' not in line and 'rows_n_lnbwd' not in line and 'rows_n_resid' not in line) or line.startswith('#'):
             continue
         f = line.split()
         try:     # columns from the right: L2hit% write_MB fetchx2 fetch_MB lds_conf% mfma_busy us n
@@ -774,7 +777,7 @@ def main():
         breakdown = {k: dict(calls=d['calls'], ms=round(d['ms'], 3), share=round(d['ms'] / tot, 4)) for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
         dom = max(agg, key=lambda k: agg[k]['ms'])
         d = dict(calls=0, ms=0.0, flops=0.0)
-        for k in NT_FAMILY:
+        for k in NT_ALL:
             for f in d:
                 d[f] += agg.get(k, {}).get(f, 0)
         peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
@@ -786,8 +789,8 @@ def main():
         intensity = fpl / traffic if traffic else None
         bound = 'hbm' if intensity is not None and intensity < peak / HBM_ACHIEVABLE_TBS else 'mfma'
         hbm_tbs = traffic / avg_s / 1e12 if traffic else None
-        roof = dict(bound=bound, kernel='mbx_gemm_nt / mbx_gemm_nt_gelu_d / mbx_gemm_nt_mul / mbx_gemm_nt_lnbwd -> gemm_nt_pp256_kernel (store, GELU + GELU\' saved, multiply epilogues) / gemm_nt_pipe_kernel (residual and LayerNorm-backward epilogues) (bf16 MFMA GEMM, every launch of a step: `launches`)', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                    traffic=traffic, traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt kernels)',
+        roof = dict(bound=bound, kernel='every A . W^T GEMM launch of a step (`launches`): mbx_gemm_nt / mbx_gemm_nt_gelu_d / mbx_gemm_nt_mul -> gemm_nt_pp256_kernel (store, GELU + GELU\' saved, multiply epilogues) / gemm_nt_pipe_kernel (residual epilogue); mbx_rows_lnbwd_t / mbx_rows_resid_ln -> rows_n_lnbwd_kernel / rows_n_resid_ln_kernel (N-resident row owners: LayerNorm backward / residual + next LayerNorm as epilogue); bf16 MFMA', achieved=round(ach, 1), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                    traffic=traffic, traffic_unit='HBM bytes per launch (launch-weighted mean over the gemm_nt and rows_n kernels)',
                     traffic_source=('STATIC: ' + os.path.relpath(PMC_TABLE, ROOT) + ' (separate rocprofv3 --pmc passes of this command on this round\'s kernels: '
                                     'FETCH_SIZE x2 + WRITE_SIZE); not measured by this run') if os.path.exists(PMC_TABLE) else None, launches=d['calls'], avg_launch_ms=round(d['ms'] / d['calls'], 4),
                     flops_per_launch=fpl, flop_per_hbm_byte=round(intensity, 1) if intensity else None,

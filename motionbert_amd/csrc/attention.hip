@@ -830,7 +830,16 @@ struct Raw4b {     // four bf16 in a uint2 -> fp32
 #ifndef MBX_ATTN_DBG
 #define MBX_ATTN_DBG 0      // ablation bits of diagnostic builds (timing only): 1 no compute loops, 2 no copy-out stores, 4 no tile / statistics loads, 8 no exp2 (p = 1)
 #endif
-template <int HD>
+// Diagnostic builds only (-DMBX_ATTN_TRACE, tools/attn_trace.py): 8 int64 per workgroup (thread 0) -- s_memrealtime (100 MHz) at entry,
+// loads of the fill issued, tiles + statistics in LDS (first barrier passed), compute done (second barrier), gradients staged (third
+// barrier), copy-out stores issued, stores acknowledged; the hardware id.  The buffer address comes from MBX_TRACE_BUF.
+#ifdef MBX_ATTN_TRACE
+__device__ long long* g_attn_trace;
+#define AT_TS(slot_) do { if (threadIdx.x == 0) ats[slot_] = (long long)wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define AT_TS(slot_) do { } while (0)
+#endif
+template <int HD, bool STATS>
 __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                  const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                  bf16_t* __restrict__ dqkv, int Tn, int J, int H, float scale,
@@ -839,6 +848,10 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
     typedef bf16_t T;
     constexpr int RSTR = rm_stride<T>(HD), CH = HD / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef MBX_ATTN_TRACE
+    long long ats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    AT_TS(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 5;
     const int C = H * HD, C3 = 3 * C;
     const Prob P = decode_prob((int)blockIdx.x, mode, Tn, J, H);
@@ -854,7 +867,7 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
     const T* qbase = qkv + P.tok0 * C3 + (size_t)P.h * HD;
     const T* dobase = d_o + P.tok0 * C + (size_t)P.h * HD;
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
-    if (st_part) fill_stat_vec<HD>(vec, st_rsum, st_bias, C, P.h, tid, 1024);
+    if (STATS) fill_stat_vec<HD>(vec, st_rsum, st_bias, C, P.h, tid, 1024);
 
     // ---- the loads of the per-query statistics (dO . O, lse: four lanes per row, KP <= 256 rows = one pass of the 1024 threads) go
     // out FIRST, so that their latency runs under the tile fill instead of after it (MBX_ATTN_STAT_EARLY=0: the old order) ----
@@ -903,6 +916,7 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
             }
         }
     }
+    AT_TS(1);
     // ---- per-query statistics: four lanes per row, each HD/4 of the d range, quad-reduced on the VALU ----
     if (!MBX_ATTN_STAT_EARLY) { ATTN_STAT_LOAD(); }
 #undef ATTN_STAT_LOAD
@@ -922,6 +936,7 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
         }
     }
     __syncthreads();
+    AT_TS(2);
 
     const int nfr = (P.L + 31) / 32;
     const float c2 = scale * 1.44269504088896341f;
@@ -931,9 +946,17 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
     for (int a = 0; a < 2 * (HD / 32); ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    const int blk = wave & 7, row = blk * 32 + (lane & 31);     // this lane's query (waves 0-7) or key (waves 8-15)
+#ifndef MBX_ATTN_SWAP
+#define MBX_ATTN_SWAP 1
+#endif
+    // (round 6, measured null: s_setprio 1 around the S / dP clusters, and around all four MFMA clusters of an iteration -- 0.8638 ->
+    // 0.8643 / 0.8743 ms; the re-cut "dQ then dV | dK" with every operand row in registers: 0.937 ms -- profiles/r06_attn_trace.txt)
+    // which waves take which role: the SIMD issues oldest wave first, and the dK + dV role is the long one (16 MFMAs per 32 x 32 block
+    // against 12, its k / v operand rows re-read from LDS) -- it goes to the OLDER waves (A/B: -DMBX_ATTN_SWAP=0 is round 2's assignment)
+    const bool qrole = MBX_ATTN_SWAP ? wave >= 8 : wave < 8;
+    const int blk = wave & 7, row = blk * 32 + (lane & 31);     // this lane's query (dQ role) or key (dK + dV role)
     if (blk < nfr && !(MBX_ATTN_DBG & 1)) {                       // L <= 256 (check_attn_args): at most eight 32-row blocks, one wave of each role per block
-        if (wave < 8) {
+        if (qrole) {
             // -------------------------------------------------------------- dQ   (lane = query)
             BReg<T, HD> qreg, doreg;
             qreg.load(reinterpret_cast<const T*>(qt + (size_t)row * RSTR), g, true);
@@ -985,14 +1008,20 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
             }
         }
     }
+    AT_TS(3);
+#ifdef MBX_ATTN_TRACE
+    if (g_attn_trace != nullptr && (threadIdx.x & 63) == 0) g_attn_trace[(size_t)gridDim.x * 9 + (size_t)blockIdx.x * 16 + (threadIdx.x >> 6)] = (long long)wall_clock64();
+#endif
     __syncthreads();                       // every wave is done reading the tiles: they become the output staging area
+    AT_TS(4);
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));         // indices for the epilogue are re-derived here, not carried through the loops (128-VGPR budget)
     const int g2 = (tid2 >> 5) & 1, row2 = blk * 32 + (tid2 & 31);
+    const bool qrole2 = MBX_ATTN_SWAP ? wave >= 8 : wave < 8;
     if (blk < nfr) {
-        if (st_part) {      // wave-uniform: each gradient row fragment goes over its own original, whose row dots it takes first
+        if (STATS) {        // each gradient row fragment goes over its own original, whose row dots it takes first
             float p1 = 0.f, p2 = 0.f;
-            if (wave < 8) {
+            if (qrole2) {
                 store_rowfrag_dot<HD>(qt_row(qt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), g2, vec, p1, p2);
             } else {
                 store_rowfrag_dot<HD>(qt_row(kt, row2, RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), g2, vec + HD / 4, p1, p2);
@@ -1002,9 +1031,9 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
             p2 = wave_halves<WaveAdd>(p2);
             if (g2 == 0 && row2 < P.L) {
                 const size_t Mtot = (size_t)(nprob / H) * P.L;
-                *reinterpret_cast<float2*>(st_part + ((size_t)(2 * P.h + (wave < 8 ? 0 : 1)) * Mtot + P.tok0 + (size_t)row2 * P.tstep) * 2) = make_float2(p1, p2);
+                *reinterpret_cast<float2*>(st_part + ((size_t)(2 * P.h + (qrole2 ? 0 : 1)) * Mtot + P.tok0 + (size_t)row2 * P.tstep) * 2) = make_float2(p1, p2);
             }
-        } else if (wave < 8) {
+        } else if (qrole2) {
             store_rowfrag<T, HD>(reinterpret_cast<T*>(qt + (size_t)row2 * RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), 1.0f, g2);
         } else {
             store_rowfrag<T, HD>(reinterpret_cast<T*>(kt + (size_t)row2 * RSTR), reinterpret_cast<const f32x16_t (&)[HD / 32]>(acc[0]), 1.0f, g2);
@@ -1012,6 +1041,7 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
         }
     }
     __syncthreads();
+    AT_TS(5);
     // ---- copy out: eight lanes write one whole 128-byte row segment of dq / dk / dv per instruction (stored straight from the
     // accumulator layout an instruction covers 32 rows x 16 bytes: measured 0.61 ms of pure memory time per launch) ----
     T* obase3 = dqkv + P.tok0 * C3 + (size_t)P.h * HD;
@@ -1035,6 +1065,17 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
             }
         }
     }
+#ifdef MBX_ATTN_TRACE
+    AT_TS(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AT_TS(7);
+    if (g_attn_trace != nullptr && threadIdx.x == 0) {
+        long long* const tr = g_attn_trace + (size_t)blockIdx.x * 9;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tr[k] = ats[k];
+        tr[8] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+#endif
 }
 
 // ================================================================================================
@@ -1133,6 +1174,12 @@ static int launch_bwd(const void* qkv, const void* o, const void* d_o, const flo
     return 0;
 }
 
+#ifdef MBX_ATTN_TRACE
+#define MBX_ATTN_TRACE_SET(s_) do { static long long* const tb = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }(); \
+                                    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_attn_trace), &tb, sizeof(tb), 0, hipMemcpyHostToDevice, (s_)); } while (0)
+#else
+#define MBX_ATTN_TRACE_SET(s_) do { } while (0)
+#endif
 static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int B, int T, int J,
                          int H, int hd, float scale, int mode, int dtype, void* stream, const float* st_bias, const float* st_rsum,
                          float* st_part, const MbxDrop& dr, void* dq_lo = nullptr) {
@@ -1151,8 +1198,9 @@ static int attn_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
         if (shm <= 160 * 1024) {
 #define MBX_BWD_FUSED(HDV)                                                                                            \
     do {                                                                                                              \
-        auto k = attn_bwd_fused_kernel<HDV>;                                                                          \
+        auto k = st_part ? attn_bwd_fused_kernel<HDV, true> : attn_bwd_fused_kernel<HDV, false>;                     \
         if (set_lds(k, shm, "attn_bwd_fused")) return 1;                                                              \
+        MBX_ATTN_TRACE_SET(s);                                                                                        \
         hipLaunchKernelGGL(k, dim3(nprob), dim3(1024), shm, s, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse, \
                            (bf16_t*)dqkv, T, J, H, scale, mode, nprob, KP, st_bias, st_rsum, st_part);                \
         MBX_LAUNCH_CHECK("attn_bwd_fused");                                                                           \
