@@ -351,22 +351,22 @@ int mbx_flip_average(const float* out2, const int* perm, float* out, int B, int 
  *     dx_t  = bf16( dres_t + rstd (dxhat - mean_k dxhat - xhat mean_k(dxhat xhat)) )          all [M,512]
  * A workgroup owns 128 complete rows (256 accumulator registers per wave), so both row means come from the accumulators; xhat bf16
  * [M,512] and rstd f32 [M] are what mbx_layernorm_fwd (gamma = NULL) left, dres_t / dx_t the gradient of the residual stream in the
- * operand type (as mbx_gemm_nt_lnbwd_t with dx = NULL).  N must be 512; K >= 512 and K % 256 == 0 (one ordinary trip of the loop in
- * front of the peeled last one); M * 1024 < 2^32 and M * K * 2 < 2^32 (32-bit lane offsets into dx_t / dy; checked).  dx_t must not alias
+ * operand type (as mbx_gemm_nt_lnbwd_t with dx = NULL).  N = 512 (K >= 512) or, round 6, N = 256 (dim_feat of MotionBERT-Lite; 128
+ * accumulator registers per wave, K >= 256), K % 256 == 0; M * N * 2 < 2^32 and M * K * 2 < 2^32 (32-bit lane offsets into dx_t / dy; checked).  dx_t must not alias
  * an input (checked for dres_t, xhat and dy).  Round 6: xhat is fetched by LDS-DMA during the last trip of the loop, in the 26 slots in
  * which the weight stream has nothing left to request (csrc/gemm_rows_n.hip). */
-size_t mbx_rows_n_pack_bytes(int K);
-/* packs n_desc operands in ONE launch (a training step re-packs 60 weights): record r of desc = {w bf16 [512,K_r], packed_r
- * (mbx_rows_n_pack_bytes(K_r) bytes), K_r} (3 x int64, device memory); max_k = the largest K_r; every K_r >= 512 and % 256 == 0 (the
- * caller's responsibility: the records live on the device). */
-int mbx_rows_n_pack_many(const int64_t* desc, int n_desc, int max_k, void* stream);
+size_t mbx_rows_n_pack_bytes(int N, int K);
+/* packs n_desc operands in ONE launch (a training step re-packs 60 weights): record r of desc = {w bf16 [N,K_r], packed_r
+ * (mbx_rows_n_pack_bytes(N, K_r) bytes), K_r} (3 x int64, device memory); N = 512 or 256 for all of them; max_k = the largest K_r; every
+ * K_r % 256 == 0 and >= 512 (N = 512) / >= 256 (N = 256) (the caller's responsibility: the records live on the device). */
+int mbx_rows_n_pack_many(const int64_t* desc, int n_desc, int N, int max_k, void* stream);
 int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* xhat, const float* rstd, const void* dres_t, void* dx_t, int M,
                      int N, int K, void* stream);
 /* The FORWARD residual GEMM of a sub-layer that is followed by a LayerNorm, on the same row-owner shape (proj / fc2 + residual,
  * DSTformer.py:241-249, and the next norm1 / norm2): y = resid + a . w^T + bias (fp32 [M,512]); xhat = (y - mean(y)) rstd(y) (bf16 [M,512],
  * the plain normalisation: gamma and beta live in the folded weights of the Linear the LayerNorm feeds), mean / rstd fp32 [M] (two-pass
- * statistics of the fp32 rows, eps inside the square root).  packed = mbx_rows_n_pack_many's image of w [512,K].  bf16; N == 512, K >= 512,
- * K % 256 == 0, M * 2048 < 2^32, M * K * 2 < 2^32 (checked).  y must not alias resid and xhat must not alias a (checked): rows past M are computed from row M - 1's
+ * statistics of the fp32 rows, eps inside the square root).  packed = mbx_rows_n_pack_many's image of w [N,K].  bf16; N = 512 (K >= 512) or
+ * 256 (K >= 256), K % 256 == 0, M * N * 4 < 2^32, M * K * 2 < 2^32 (checked).  y must not alias resid and xhat must not alias a (checked): rows past M are computed from row M - 1's
  * inputs and stored onto row M - 1 again, which is only harmless while those inputs are still the original ones. */
 int mbx_rows_resid_ln(const void* a, const void* packed, const float* bias, const float* resid, float* y, void* xhat, float* mean,
                       float* rstd, float eps, int M, int N, int K, void* stream);

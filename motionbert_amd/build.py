@@ -21,6 +21,14 @@ LIB = os.path.join(HERE, 'libmbx.so')
 SOURCES = ['elementwise.hip', 'gemm.hip', 'gemm_pipe.hip', 'mlp_fused.hip', 'gemm_rows.hip', 'gemm_rows_n.hip', 'attention.hip', 'train_step.hip', 'augment.hip', 'probe.hip']
 HEADERS = [os.path.join(CSRC, 'mbx_common.h'), os.path.join(CSRC, 'gelu_fast.h'), os.path.join(CSRC, 'lds_stream.h'), os.path.join(os.path.dirname(HERE), 'include', 'mbx.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
+# per-source additions.  gemm_rows_n.hip: the body of the trip loop (32 slots with their folded-after-unrolling switches) x 4 or 8 stages
+# exceeds LLVM's default size limit for `#pragma unroll` in the 8-tile instantiation -- the loop then stays rolled, the token ring is
+# indexed at run time and becomes a 272-byte stack object (tests/test_library_abi.py::test_device_code_policy would reject the scratch)
+EXTRA_FLAGS = {'gemm_rows_n.hip': ['-mllvm', '-pragma-unroll-threshold=65536']}
+
+
+def flags_for(src: str):
+    return FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
 
 
 def _hipcc():
@@ -49,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+        cmd = [hipcc] + flags_for(s) + ['-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -49,21 +49,50 @@ __device__ long long* g_rn_trace;
 #define RN_TS(slot_) do { } while (0)
 #endif
 static constexpr int RN_BM = 128;              // token rows per workgroup (4 waves x 32)
-static constexpr int RN_N = 512;               // output columns = the accumulators of a wave (16 tiles of 32)
-static constexpr int RN_STAGE = 32 * 1024;     // one ring stage = 32 fragments = 2 k-steps x 16 column tiles
+static constexpr int RN_STAGE = 32 * 1024;     // one ring stage = 32 fragments = KPS k-steps x NT column tiles
 static constexpr int RN_RING = 4 * RN_STAGE;
+// Geometry of the N = 32 NT output columns a wave owns completely.  NT = 16: dim_feat 512, 256 accumulator registers, a stage = 2 k-steps;
+// NT = 8 (round 6): dim_feat 256 -- MotionBERT-Lite, configs/pretrain/MB_lite.yaml:18-24 -- 128 accumulator registers, a stage = 4 k-steps.
+// A trip of the loop is always 16 k-steps (the token ring's indices are then static): 8 or 4 stages.
+// The token fragments of a stage must be OLDER in the in-order counter than the last weight piece of that stage (requested in slot 23, two
+// stages ahead): then the barrier's counted wait for the pieces covers them and the token registers need no wait of their own.  NT = 16:
+// requested LA = 4 stages ahead, in slots 25 and 29; NT = 8: a stage has four k-steps, the ring of 16 holds four stages, so LA = 3 and the
+// slots 1, 5, 9, 13 -- in FRONT of slot 23.  (Requested two stages ahead in the slots 17..29, as first built, the tokens are younger than
+// the piece the barrier waits for: 4131 rows passed, 264,384 rows came back with a handful of wrong ones.)
+template <int NT> struct RnGeo {
+    static constexpr int N = 32 * NT, KPS = 32 / NT, TRIP = 16 / KPS, NQ = NT / 4;
+    static constexpr int LA = NT == 16 ? 4 : 3, TS0 = NT == 16 ? 25 : 1;      // token lookahead in stages; slot of a stage's first token request
+};
+// Counted wait at the barrier of stage u of a trip (slot 27): "stage q + 1 has landed" leaves the operations issued behind its last piece
+// (slot 23 of stage q - 2) in flight -- every stage issues 8 pieces (P) and, unless the stage it fetches for lies behind the LAST trip, KPS
+// token fragments (T) in the slots ts0, ts0 + 4, ....  The first two stages of EVERY trip use the counts of the first trip, whose
+// predecessors are the preamble's tokens, 24 P + 2 P (a slightly stronger wait on later trips, no branch).
+__host__ __device__ constexpr int rn_cnt(int kps, int trip, int la, int ts0, bool last, int u) {
+    int t_lo = 0, t_hi = 0;                        // the token requests of a stage in front of slot 27 / behind slot 23
+    for (int j = 0; j < kps; ++j) { t_lo += ts0 + 4 * j < 27; t_hi += ts0 + 4 * j > 23; }
+    const bool t2 = !last || u - 2 + la < trip, t1 = !last || u - 1 + la < trip, t0 = !last || u + la < trip;
+    if (u == 0) return 8 + 2 + 6 + (t0 ? t_lo : 0);
+    if (u == 1) return 2 + (8 + (t1 ? kps : 0)) + 6 + (t0 ? t_lo : 0);
+    return (2 + (t2 ? t_hi : 0)) + (8 + (t1 ? kps : 0)) + (6 + (t0 ? t_lo : 0));
+}
+static_assert(rn_cnt(2, 8, 4, 25, false, 2) == 21 && rn_cnt(2, 8, 4, 25, true, 0) == 17 && rn_cnt(2, 8, 4, 25, true, 1) == 19 &&
+              rn_cnt(2, 8, 4, 25, true, 3) == 21 && rn_cnt(2, 8, 4, 25, true, 4) == 20 && rn_cnt(2, 8, 4, 25, true, 5) == 18 &&
+              rn_cnt(2, 8, 4, 25, true, 7) == 16, "the counts of round 5, by hand");
+static_assert(rn_cnt(4, 4, 3, 1, false, 0) == 20 && rn_cnt(4, 4, 3, 1, false, 1) == 24 && rn_cnt(4, 4, 3, 1, false, 3) == 24 &&
+              rn_cnt(4, 4, 3, 1, true, 0) == 20 && rn_cnt(4, 4, 3, 1, true, 1) == 20 && rn_cnt(4, 4, 3, 1, true, 2) == 16 &&
+              rn_cnt(4, 4, 3, 1, true, 3) == 16, "the counts of the 8-tile geometry, by hand");
 
-// packed stream: fragment (kk, nt) at index kk * 16 + nt; lane (i, g) owns bytes [16 l, 16 l + 16) = w[32 nt + i][16 kk + 8 g + t],
-// t = 0..7, w = the [512, K] row-major operand of mbx_gemm_nt (for dX: the transposed folded weight W'^T)
-// One launch packs many operands: record r of `desc` = {src bf16 [512, K], dst, K} (3 x int64); blockIdx.y = record
-__global__ __launch_bounds__(256) void rows_n_pack_many_kernel(const int64_t* __restrict__ desc) {
+// packed stream: fragment (kk, nt) at index kk * NT + nt; lane (i, g) owns bytes [16 l, 16 l + 16) = w[32 nt + i][16 kk + 8 g + t],
+// t = 0..7, w = the [32 NT, K] row-major operand of mbx_gemm_nt (for dX: the transposed folded weight W'^T)
+// One launch packs many operands: record r of `desc` = {src bf16 [32 NT, K], dst, K} (3 x int64); blockIdx.y = record
+__global__ __launch_bounds__(256) void rows_n_pack_many_kernel(const int64_t* __restrict__ desc, int NT) {
     const int64_t* d = desc + (size_t)blockIdx.y * 3;
     const bf16_t* w = reinterpret_cast<const bf16_t*>(d[0]);
     bf16_t* out = reinterpret_cast<bf16_t*>(d[1]);
     const int K = (int)d[2];
     const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (frag >= (K / 16) * 16) return;
-    const int kk = frag >> 4, nt = frag & 15, i = lane & 31, g = lane >> 5;
+    if (frag >= (K / 16) * NT) return;
+    const int kk = frag / NT, nt = frag % NT, i = lane & 31, g = lane >> 5;
     *reinterpret_cast<uint4*>(out + (size_t)frag * 512 + lane * 8) = *reinterpret_cast<const uint4*>(w + (size_t)(32 * nt + i) * K + 16 * kk + 8 * g);
 }
 
@@ -79,11 +108,22 @@ __device__ __forceinline__ void rn_glds(const char* base, unsigned voff, unsigne
     }
 }
 template <int N> __device__ __forceinline__ void rn_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+// the same with a count that is known only after unrolling (an asm "n" operand must be a constant at parse time: the switch folds)
+__device__ __forceinline__ void rn_vmwait_n(int n) {
+    switch (n) {
+#define RW_(v_) case v_: asm volatile("s_waitcnt vmcnt(" #v_ ")" ::: "memory"); break;
+        RW_(8) RW_(10) RW_(16) RW_(17) RW_(18) RW_(19) RW_(20) RW_(21) RW_(22) RW_(23) RW_(24) RW_(25) RW_(26) RW_(32)
+#undef RW_
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // (a count the schedule does not produce: the strongest wait)
+    }
+}
 
+template <int NT>
 __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __restrict__ dy, const char* __restrict__ wpk,
                                                              const bf16_t* __restrict__ xhat, const float* __restrict__ rstd,
                                                              const bf16_t* __restrict__ dres_t, bf16_t* __restrict__ dx_t, int M, int K) {
     constexpr int PF = 5;
+    constexpr int RN_N = RnGeo<NT>::N, KPS = RnGeo<NT>::KPS, TRIP = RnGeo<NT>::TRIP, NQ = RnGeo<NT>::NQ, LA = RnGeo<NT>::LA, TS0 = RnGeo<NT>::TS0;
     extern __shared__ __attribute__((aligned(16))) char ring[];
 #ifdef MBX_RN_TRACE
     long long tsr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -95,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     const unsigned fr = (unsigned)(uintptr_t)(const lds_void_t*)ring + lane * 16;
     const unsigned wvo = wave * 1024 + lane * 16;
     const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
-    const int nstages = K / 32;
+    const int nstages = K / (16 * KPS);
     // stage q of the stream (past the end: a harmless re-read of the last stage into a slot nobody reads again)
 #define RN_ISSUE(q_, j_) glds16_s(wpk + (size_t)min((q_), nstages - 1) * RN_STAGE + (j_) * 4096, wvo, dl + ((q_) & 3) * RN_STAGE + (j_) * 4096)
     // token fragments: lane (i, g) = 16 bytes of row i at k = 16 s + 8 g; rows past M repeat row M - 1 (their results are never stored)
@@ -114,26 +154,29 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     unsigned xoff[8];                              // byte offset of (row 4 r4 + xr, piece xp ^ (row & 15) of quarter 0) in xhat / dres / dx
 #pragma unroll
     for (int r4 = 0; r4 < 8; ++r4) xoff[r4] = (unsigned)min(mw + 4 * r4 + xr, M - 1) * (RN_N * 2) + ((xp ^ ((4 * r4 + xr) & 15)) << 4);
-    {
+    if constexpr (8 * NQ > 26) {                   // (NT = 8: xhat is 16 KiB per wave, all of it fits the 26 slots)
         const unsigned bdl0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const lds_void_t*)ring + RN_RING + wave * 8192);
 #pragma unroll
         for (int r4 = 2; r4 < 8; ++r4) glds16_s(reinterpret_cast<const char*>(xhat) + 3 * 256, xoff[r4], bdl0 + r4 * 1024);
     }
+#define RN_DP_OK(n_) ((n_) < 8 * NQ)               /* (past xhat's last piece the slot re-reads the last stage, as in round 5) */
 #define RN_DPIECE(n_, sp_) rn_glds(reinterpret_cast<const char*>(xhat) + ((n_) >> 3) * 256, xoff[(n_) & 7], dlu, sp_)
     u32x4_t tok[16];                               // fragment s lives in tok[s & 15]
-#define RN_TOK(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst_) : "v"(aoff), "s"(ap), "n"(off_) : "memory")
+// (the byte offset of the k-step goes into the scalar base -- two SALU instructions per load: inside a template an asm "n" operand is checked
+// at instantiation and must be a constant expression there, which an index of an unrolled loop is not)
+#define RN_TOK(dst_, off_) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst_) : "v"(aoff), "s"(ap + (off_)) : "memory")
 #define RN_TOKN(dst_, off_) RN_TOK(dst_, (off_) + 512)      /* the tokens of the next trip's first half */
-    RN_TOK(tok[0], 0); RN_TOK(tok[1], 32); RN_TOK(tok[2], 64); RN_TOK(tok[3], 96);
-    RN_TOK(tok[4], 128); RN_TOK(tok[5], 160); RN_TOK(tok[6], 192); RN_TOK(tok[7], 224);
+#pragma unroll
+    for (int ks = 0; ks < KPS * LA; ++ks) RN_TOK(tok[ks], 32 * ks);        // the k-steps of the first LA stages
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j) RN_ISSUE(q, j);
     RN_ISSUE(3, 0);
     RN_ISSUE(3, 1);
-    f32x16_t acc[16];
+    f32x16_t acc[NT];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
         asm volatile("" : "+a"(acc[t]));            // zeroed in the accumulator file while the first loads are in flight
@@ -146,13 +189,16 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     u32x4_t fb[8];
 #pragma unroll
     for (int k = 0; k < PF; ++k) fb[k] = lds_read16(fr, k * 1024);
-    // ---- the product: trips of 8 stages = 16 k-steps (the token ring's indices are then static); K % 256 == 0, K >= 512.
-    // Counted waits of the LAST trip: there is no next trip to fetch tokens for, so its second half issues 8 P and no T per stage; the
-    // barrier of its stage u sees 17, 19, 21, 21, 20, 18, 16, 16 younger operations.
+    // ---- the product: trips of TRIP stages = 16 k-steps (the token ring's indices are then static); K % 256 == 0.
+    // Slot k of a stage: column tile k % NT, k-step k / NT of the stage's KPS.  The token fragments of k-step ks = KPS (u + LA) + j -- LA
+    // stages ahead, RnGeo -- are requested in slot TS0 + 4 j of stage u: from this trip's rows while ks < 16, from the next trip's beyond
+    // (not in the LAST trip: a register an asm load writes but nobody reads is dead to the compiler, which hands it to something else --
+    // and the load lands in it later).
     const unsigned dlu = __builtin_amdgcn_readfirstlane(dl);      // (wave-uniform by construction; said again for the "s" operands below)
+#define RN_KS(u_, k_) (KPS * ((u_) + LA) + ((k_) - TS0) / 4)      /* the k-step whose tokens slot k of stage u requests */
 #define RN_TRIP(LAST_, DP_)                                                                                                 \
     {                                                                                                                \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                              \
+        _Pragma("unroll") for (int u = 0; u < TRIP; ++u) {                                                           \
             const int q = q0 + u;                                                                                    \
             unsigned st = fr + (u & 3) * RN_STAGE, sn = fr + ((u + 1) & 3) * RN_STAGE;                               \
             asm volatile("" : "+v"(st), "+v"(sn));                                                                   \
@@ -160,30 +206,29 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             const char* const n4 = wpk + (size_t)min(q + 4, nstages - 1) * RN_STAGE;                                 \
             _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                         \
                 if (k == 32 - PF) {                                                                                  \
-                    if (LAST_) { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else if (u < 4) rn_vmwait<21>(); \
-                                 else if (u == 4) rn_vmwait<20>(); else if (u == 5) rn_vmwait<18>(); else rn_vmwait<16>(); }      \
-                    else { if (u == 0) rn_vmwait<17>(); else if (u == 1) rn_vmwait<19>(); else rn_vmwait<21>(); }    \
+                    rn_vmwait_n(rn_cnt(KPS, TRIP, LA, TS0, LAST_, u));                                               \
                     __builtin_amdgcn_sched_barrier(0);                                                               \
                     __builtin_amdgcn_s_barrier();                                                                    \
                     __builtin_amdgcn_sched_barrier(0);                                                               \
                 }                                                                                                    \
                 fb[(k + PF) & 7] = k + PF < 32 ? lds_read16(st, (k + PF) * 1024) : lds_read16(sn, (k + PF - 32) * 1024); \
-                /* slot k: k-step (k >> 4) of the stage, column tile k & 15 */                                       \
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[k & 15]) : "v"(fb[k & 7]), "v"(tok[(2 * u + (k >> 4)) & 15])); \
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[k % NT]) : "v"(fb[k & 7]), "v"(tok[(KPS * u + k / NT) & 15])); \
                 if ((k & 3) == 3) {                                                                                  \
-                    /* LAST trip, from slot 27 of stage 4 on: the stream has no stage q + 4 / q + 3 left, and the ring slot such a   \
-                       piece would go to is never read again (it used to be a re-read of the last stage, so that the wait counts     \
-                       stay constant).  DP_: piece n = 0..25 of the EPILOGUE's input goes there instead -- same position in the     \
-                       in-order counter, so no counted wait changes -- into the wave's KiB of ring slot n >> 3, piece n & 7 */        \
-                    if (LAST_ && DP_ && k < 24 && u >= 5) RN_DPIECE(8 * (u - 5) + (k >> 2) + 2, ((u + 3) & 3) * 8 + (k >> 2) + 2);   \
-                    else if (LAST_ && DP_ && k >= 24 && u >= 4) RN_DPIECE(8 * (u - 4) + (k >> 2) - 6, ((u + 4) & 3) * 8 + (k >> 2) - 6); \
+                    /* LAST trip, from slot 27 of stage TRIP - 4 on: the stream has no stage q + 4 / q + 3 left, and the ring slot     \
+                       such a piece would go to is never read again (it used to be a re-read of the last stage, so that the wait     \
+                       counts stay constant).  DP_: piece n = 0..25 of the EPILOGUE's input goes there instead -- same position in   \
+                       the in-order counter, so no counted wait changes -- into the wave's KiB of ring slot n >> 3, piece n & 7 */     \
+                    if (LAST_ && DP_ && k < 24 && u >= TRIP - 3 && RN_DP_OK(8 * (u - (TRIP - 3)) + (k >> 2) + 2))                    \
+                        RN_DPIECE(8 * (u - (TRIP - 3)) + (k >> 2) + 2, ((u + 3) & 3) * 8 + (k >> 2) + 2);                            \
+                    else if (LAST_ && DP_ && k >= 24 && u >= TRIP - 4 && RN_DP_OK(8 * (u - (TRIP - 4)) + (k >> 2) - 6))              \
+                        RN_DPIECE(8 * (u - (TRIP - 4)) + (k >> 2) - 6, ((u + 4) & 3) * 8 + (k >> 2) - 6);                            \
                     else if (k < 24) rn_glds(n3 + ((k >> 2) + 2) * 4096, wvo, dlu, ((u + 3) & 3) * 8 + (k >> 2) + 2);                \
                     else rn_glds(n4 + ((k >> 2) - 6) * 4096, wvo, dlu, ((u + 4) & 3) * 8 + (k >> 2) - 6);                             \
                 }                                                                                                    \
-                /* (no token loads in the second half of the LAST trip: a register an asm load writes but nobody reads is dead to the   \
-                   compiler, which hands it to something else -- and the load lands in it later) */                                     \
-                if (k == 25) { if (u < 4) RN_TOK(tok[(2 * (u + 4)) & 15], 32 * (2 * (u + 4))); else if (!LAST_) RN_TOKN(tok[(2 * (u + 4)) & 15], 32 * (2 * (u - 4))); } \
-                if (k == 29) { if (u < 4) RN_TOK(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u + 4) + 1)); else if (!LAST_) RN_TOKN(tok[(2 * (u + 4) + 1) & 15], 32 * (2 * (u - 4) + 1)); } \
+                if ((k & 3) == 1 && k >= TS0 && k < TS0 + 4 * KPS) {                                                 \
+                    if (u + LA < TRIP) RN_TOK(tok[RN_KS(u, k) & 15], 32 * (RN_KS(u, k) & 15));                       \
+                    else if (!LAST_) RN_TOKN(tok[RN_KS(u, k) & 15], 32 * (RN_KS(u, k) & 15));                        \
+                }                                                                                                    \
                 __builtin_amdgcn_sched_barrier(0);                                                                   \
             }                                                                                                        \
         }                                                                                                            \
@@ -191,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     }
     int q0 = 0;
     if (!(MBX_RN_DBG & 2)) {
-        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
+        for (; q0 + TRIP < nstages; q0 += TRIP) RN_TRIP(false, false)
         RN_TRIP(true, true)
     }
     RN_TS(2);
@@ -202,8 +247,11 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     RN_TS(3);
     if (MBX_RN_DBG & 1) return;
     // ONE pad for all sixteen tiles (the wait states between the last MFMA and the first non-MFMA reader of its result)
-    asm volatile("s_nop 15" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]),
-                 "+a"(acc[8]), "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]), "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15]));
+    if constexpr (NT == 16)
+        asm volatile("s_nop 15" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]),
+                     "+a"(acc[8]), "+a"(acc[9]), "+a"(acc[10]), "+a"(acc[11]), "+a"(acc[12]), "+a"(acc[13]), "+a"(acc[14]), "+a"(acc[15]));
+    else
+        asm volatile("s_nop 15" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]));
     // ---- epilogue.  xhat is on chip: piece n = 8 j + r4 in the wave's KiB of (ring slot n >> 3, piece n & 7) for n < 26 and in KiB r4 of
     // the wave's fifth buffer for n >= 26; inside a KiB row r takes 256 bytes, its 16-byte piece p sits at slot p ^ (r & 15), and a lane
     // reads its accumulator positions (row i, columns 32 ntl + 8 qq + 4 g + e of the quarter) as 8-byte halves of pieces.  The wave's other
@@ -231,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     // ... and for the lane's own row i (KiB i >> 2, row i & 3 of it) in the accumulator layout
     const int ck = i_e >> 2, inr = (i_e & 3) * 256 + 8 * g_e, sx = (i_e & 15) << 4;
     char* const xc_i = rw + ck * 4096 + inr;                          // + j * 32768 for quarters 0..2
-    char* const xc3_i = (ck < 2 ? rw + 3 * 32768 + ck * 4096 : bd + ck * 1024) + inr;
+    char* const xc3_i = (ck < 2 ? rw + 3 * 32768 + ck * 4096 : bd + ck * 1024) + inr;      // (quarter 3: NT = 16 only)
     const char* const dx_ = (ck < 2 ? bd + ck * 1024 : rw + 3 * 32768 + ck * 4096) + inr;
     // DMA instruction r4 of a quarter of dres: the same rows and pieces as of xhat
     unsigned doff[8];
@@ -249,18 +297,19 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     // (the four reads of tile nt + 1 are issued in front of the arithmetic of tile nt.  One wave per SIMD means nothing else covers a
     // ds_read -> use pair: as written in round 5 every tile of both passes waited out its own LDS round trip, 228 s_waitcnt in 2700 VALU
     // instructions -- profiles/r06_rows_n_ablation.txt)
-#define RN_XRD(nt_, qq_) (*reinterpret_cast<const uint2*>(((nt_) < 12 ? xc_i + ((nt_) >> 2) * 32768 : xc3_i) + (((((nt_) & 3) * 4 + (qq_)) << 4) ^ sx)))
+#define RN_XRD(nt_, qq_) (*reinterpret_cast<const uint2*>(((nt_) < 12 ? xc_i + ((nt_) >> 2) * 32768 : xc3_i) + (((((nt_) & 3) * 4 + (qq_)) << 4) ^ sx)))      /* (NT = 8: nt < 8) */
     uint2 xq[2][4];
     // Counted waits for xhat, in issue order  ... | n0 .. n7 | n8 .. n15 | n16 .. n23 | n24 n25 | D0 (8) [| rstd]: quarter j of xhat (pieces
-    // 8 j .. 8 j + 7; 26..31 are the oldest operations of the kernel) has landed when at most 26 / 18 / 10 / 8 younger operations are
-    // in flight.  (The compiler's load of rstd sits behind D0 in program order; if it is there the waits are one stronger than needed.)
+    // 8 j .. 8 j + 7; 26..31 are the oldest operations of the kernel; NT = 8: the slots 16..25 re-read the last stage) has landed when at
+    // most 26 / 18 / 10 / 8 younger operations are in flight.  (The compiler's load of rstd sits behind D0 in program order; if it is
+    // there the waits are one stronger than needed.)
     rn_vmwait<26>();
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) xq[0][qq] = RN_XRD(0, qq);
 #pragma unroll
-    for (int nt = 0; nt < 16; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         if (nt == 3) rn_vmwait<18>(); else if (nt == 7) rn_vmwait<10>(); else if (nt == 11) rn_vmwait<8>();
-        if (nt + 1 < 16) {
+        if (nt + 1 < NT) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) xq[(nt + 1) & 1][qq] = RN_XRD(nt + 1, qq);
         }
@@ -280,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
     const float k1 = -rs * c1, k2 = -rs * c2;                         // dx = dres + rs t + k1 + k2 xhat
     RN_TS(5);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NQ; ++j) {
         // vector memory operations younger than the DMA of quarter j: the stores of quarter j - 1 (8)
         if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #define RN_DRD(ntl_, qq_) (*reinterpret_cast<const uint2*>(dx_ + ((((ntl_) * 4 + (qq_)) << 4) ^ sx)))
@@ -310,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // dres has been read (its image is free), dx is in place
-        if (j == 0) { RN_DDMA(1); } else if (j == 1) { RN_DDMA(2); } else if (j == 2) { RN_DDMA(3); }
+        if (j + 1 < NQ) { if (j == 0) { RN_DDMA(1); } else if (j == 1) { RN_DDMA(2); } else if (j == 2) { RN_DDMA(3); } }
 #pragma unroll
         for (int r4 = 0; r4 < 8; ++r4) {
             const int rl = 4 * r4 + xr_e;
@@ -347,11 +396,13 @@ __global__ __launch_bounds__(256, 1) void rows_n_lnbwd_kernel(const bf16_t* __re
 // (Measured and dropped: the first two quarters of resid requested into registers during the last trip of the loop, as the xhat
 // prefetch of the kernel above -- 0.380 -> 0.381 ms at K = 512, 0.465 -> 0.490 at K = 1024: across the CUs this kernel is bound by
 // HBM bandwidth (mixed reads and writes at ~4.2 TB/s of algorithmic bytes), not by the latency of one tile's loads.)
+template <int NT>
 __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* __restrict__ a, const char* __restrict__ wpk,
                                                                 const float* __restrict__ bias, const float* __restrict__ resid,
                                                                 float* __restrict__ y, bf16_t* __restrict__ xhat_o,
                                                                 float* __restrict__ mean_o, float* __restrict__ rstd_o, float eps, int M, int K) {
     constexpr int PF = 5;
+    constexpr int RN_N = RnGeo<NT>::N, KPS = RnGeo<NT>::KPS, TRIP = RnGeo<NT>::TRIP, NQ = RnGeo<NT>::NQ, LA = RnGeo<NT>::LA, TS0 = RnGeo<NT>::TS0;
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
@@ -360,29 +411,29 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     const unsigned wvo = wave * 1024 + lane * 16;
     const unsigned dl = (unsigned)(uintptr_t)(const lds_void_t*)ring + wave * 1024;
     const unsigned dlu = __builtin_amdgcn_readfirstlane(dl);
-    const int nstages = K / 32;
+    const int nstages = K / (16 * KPS);
     const char* ap = reinterpret_cast<const char*>(a);
     const unsigned aoff = ((unsigned)min(mw + i, M - 1) * (unsigned)K + 8u * g) * 2u;
     // the wave's copy of the bias (8 floats per lane), requested first -- the oldest vector memory operations of the kernel, so no
     // counted wait below changes -- and parked in the wave's fifth buffer after the loop (the wait there carries the dependence)
     u32x4_t bq0, bq1;
     {
-        const float* const bp = bias + lane * 8;
+        const float* const bp = bias + (lane & (RN_N / 8 - 1)) * 8;      // (NT = 8: 256 floats, the upper half wave repeats the lower)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq0) : "v"(bp) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(bq1) : "v"(bp) : "memory");
     }
     u32x4_t tok[16];
-    RN_TOK(tok[0], 0); RN_TOK(tok[1], 32); RN_TOK(tok[2], 64); RN_TOK(tok[3], 96);
-    RN_TOK(tok[4], 128); RN_TOK(tok[5], 160); RN_TOK(tok[6], 192); RN_TOK(tok[7], 224);
+#pragma unroll
+    for (int ks = 0; ks < KPS * LA; ++ks) RN_TOK(tok[ks], 32 * ks);        // the k-steps of the first LA stages
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j) RN_ISSUE(q, j);
     RN_ISSUE(3, 0);
     RN_ISSUE(3, 1);
-    f32x16_t acc[16];                              // acc[nt][4 qq + e] = out[row i][32 nt + 8 qq + 4 g + e]
+    f32x16_t acc[NT];                              // acc[nt][4 qq + e] = out[row i][32 nt + 8 qq + 4 g + e]
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
         asm volatile("" : "+a"(acc[t]));
@@ -402,10 +453,12 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
 #pragma unroll
     for (int d = 0; d < 16; ++d) doff[d] = (unsigned)min(mw + 2 * d + g, M - 1) * (RN_N * 4) + ((i ^ (2 * d + g)) << 4);
 #undef RN_DPIECE
+#undef RN_DP_OK
+#define RN_DP_OK(n_) true
 #define RN_DPIECE(n_, sp_) rn_glds(reinterpret_cast<const char*>(resid) + ((n_) >> 4) * 512, doff[(n_) & 15], dlu, sp_)
     int q0 = 0;
     if (!(MBX_RN_DBG & 2)) {
-        for (; q0 + 8 < nstages; q0 += 8) RN_TRIP(false, false)
+        for (; q0 + TRIP < nstages; q0 += TRIP) RN_TRIP(false, false)
         RN_TRIP(true, true)
     }
     // (no drain of the vector memory counter: the KiBs of resid requested in the last stages are still on their way; counted wait below.
@@ -414,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     __builtin_amdgcn_s_barrier();                                    // every wave is done with the ring
     if (MBX_RN_DBG & 1) return;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) MFMA_PAD_A(acc[t]);
+    for (int t = 0; t < NT; ++t) MFMA_PAD_A(acc[t]);
 
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
@@ -445,10 +498,10 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     const int sx = i_e << 4;
     float s1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // vector memory operations younger than the last DMA of quarter j, in issue order  R1' (6) | S0 (16) R2 (16) | S1 R3 | S2 | S3:
-        // quarter 0: waited for above
-        if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else if (j == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    for (int j = 0; j < NQ; ++j) {
+        // vector memory operations younger than the last DMA of quarter j, in issue order  R1' (6) | S0 (16) R2 (16) | S1 R3 | S2 | S3
+        // (NT = 8: R1' | S0 | S1): the stores of quarter j - 1 and, if there is one, the DMA of quarter j + 1.  Quarter 0: waited for above
+        if (j >= 1) rn_vmwait_n(j + 1 < NQ ? 32 : 16);
         char* const rbj = rb_i + (j & 1) * 65536;
 #define RN_RRD(ntl_, qq_) (*reinterpret_cast<const float4*>(rbj + (((8 * (ntl_) + 2 * (qq_) + g_e) << 4) ^ sx)))
 #define RN_BRD(ntl_, qq_) (*reinterpret_cast<const float4*>(bx + (32 * (4 * j + (ntl_)) + 8 * (qq_) + 4 * g_e) * 4))
@@ -483,13 +536,13 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
             *reinterpret_cast<float4*>(reinterpret_cast<char*>(y) + doff_e[d] + j * 512) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the image has been read out
-        if (j == 0) { RN_RDMA(2, 0, 0); } else if (j == 1) { RN_RDMA(3, 1, 0); }
+        if (j + 2 < NQ) { if (j == 0) { RN_RDMA(2, 0, 0); } else if (j == 1) { RN_RDMA(3, 1, 0); } }
     }
     // LayerNorm statistics of the 512 values of row i (lanes i and i + 32 hold its halves): two passes, as ln_fwd_row
     const float mu = wave_halves<WaveAdd>(s1) * (1.0f / (float)RN_N);
     float s2 = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 16; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const f32x16_t t = acc[nt];
 #pragma unroll
         for (int e = 0; e < 16; ++e) { const float c = t[e] - mu; s2 = fmaf(c, c, s2); }
@@ -503,7 +556,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     char* const xw_i = rw + (i_e >> 2) * 4096 + (i_e & 3) * 256 + 8 * g_e;
     const int sxh = (i_e & 15) << 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NQ; ++j) {
 #pragma unroll
         for (int ntl = 0; ntl < 4; ++ntl) {
             const f32x16_t t = acc[4 * j + ntl];
@@ -516,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NQ; ++j) {
 #pragma unroll
         for (int r4 = 0; r4 < 8; ++r4) {
             const int rl = 4 * r4 + xr_e;
@@ -531,32 +584,43 @@ __global__ __launch_bounds__(256, 1) void rows_n_resid_ln_kernel(const bf16_t* _
 }
 
 // ---- C ABI -------------------------------------------------------------------------------------------------------------------
-extern "C" size_t mbx_rows_n_pack_bytes(int K) { return (size_t)RN_N * K * sizeof(bf16_t); }
+extern "C" size_t mbx_rows_n_pack_bytes(int N, int K) { return (size_t)N * K * sizeof(bf16_t); }
 
-extern "C" int mbx_rows_n_pack_many(const int64_t* desc, int n_desc, int max_k, void* stream) {
+extern "C" int mbx_rows_n_pack_many(const int64_t* desc, int n_desc, int N, int max_k, void* stream) {
     MBX_CHECK_ARG(desc && n_desc > 0, "rows_n_pack_many: bad arguments");
-    MBX_CHECK_ARG(max_k >= 512 && max_k % 256 == 0, "rows_n_pack_many: max_k=%d (%% 256, >= 512)", max_k);
-    hipLaunchKernelGGL(rows_n_pack_many_kernel, dim3(((max_k / 16) * 16 + 3) / 4, n_desc), dim3(256), 0, (hipStream_t)stream, desc);
+    MBX_CHECK_ARG((N == 512 || N == 256) && max_k >= 256 && max_k % 256 == 0, "rows_n_pack_many: N=%d (256 or 512), max_k=%d (%% 256)", N, max_k);
+    hipLaunchKernelGGL(rows_n_pack_many_kernel, dim3(((max_k / 16) * (N / 32) + 3) / 4, n_desc), dim3(256), 0, (hipStream_t)stream, desc, N / 32);
     MBX_LAUNCH_CHECK("rows_n_pack_many");
     return 0;
 }
 
+// shapes both kernels take: N = 512 (16 column tiles per wave; K >= 512: one ordinary trip in front of the peeled last one, as tested since
+// round 5) or N = 256 (8 tiles; K >= 256: MotionBERT-Lite's proj contracts over 256 channels, a single -- the peeled -- trip)
+#define RN_CHECK_SHAPE(who_)                                                                                         \
+    MBX_CHECK_ARG(M > 0 && ((N == 512 && K >= 512) || (N == 256 && K >= 256)) && K % 256 == 0,                      \
+                  who_ ": bad shape M=%d N=%d (512 with K >= 512, or 256 with K >= 256) K=%d (%% 256)", M, N, K)
+
 extern "C" int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* xhat, const float* rstd, const void* dres_t, void* dx_t,
                                 int M, int N, int K, void* stream) {
     MBX_CHECK_ARG(dy && packed && xhat && rstd && dres_t && dx_t, "rows_lnbwd_t: null pointer");
-    MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 512 && K % 256 == 0, "rows_lnbwd_t: bad shape M=%d N=%d (512) K=%d (%% 256, >= 512)", M, N, K);
-    MBX_CHECK_ARG((size_t)M * RN_N * 2 < ((size_t)1 << 32), "rows_lnbwd_t: M=%d rows of 1 KiB exceed the 32-bit row offsets of the kernel", M);
+    RN_CHECK_SHAPE("rows_lnbwd_t");
+    MBX_CHECK_ARG((size_t)M * N * 2 < ((size_t)1 << 32), "rows_lnbwd_t: M=%d rows of %d bytes exceed the 32-bit row offsets of the kernel", M, N * 2);
     MBX_CHECK_ARG((size_t)M * K * 2 < ((size_t)1 << 32), "rows_lnbwd_t: dy of M=%d x K=%d exceeds the 32-bit lane offsets of the kernel", M, K);
     MBX_CHECK_ARG(dx_t != dres_t && dx_t != xhat && dx_t != dy, "rows_lnbwd_t: dx_t aliases an input (rows past M re-read row M - 1 after it was stored)");
-    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_lnbwd_kernel), RN_RING + 4 * 8192, "rows_lnbwd_t")) return 1;
+    const void* kern = N == 512 ? reinterpret_cast<const void*>(rows_n_lnbwd_kernel<16>) : reinterpret_cast<const void*>(rows_n_lnbwd_kernel<8>);
+    if (mbx_set_dyn_lds(kern, RN_RING + 4 * 8192, "rows_lnbwd_t")) return 1;
 #ifdef MBX_RN_TRACE
     {
         static long long* const tb = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rn_trace), &tb, sizeof(tb), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
     }
 #endif
-    hipLaunchKernelGGL(rows_n_lnbwd_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const char*)packed, (const bf16_t*)xhat, rstd, (const bf16_t*)dres_t, (bf16_t*)dx_t, M, K);
+    if (N == 512)
+        hipLaunchKernelGGL(rows_n_lnbwd_kernel<16>, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)dy,
+                           (const char*)packed, (const bf16_t*)xhat, rstd, (const bf16_t*)dres_t, (bf16_t*)dx_t, M, K);
+    else
+        hipLaunchKernelGGL(rows_n_lnbwd_kernel<8>, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)dy,
+                           (const char*)packed, (const bf16_t*)xhat, rstd, (const bf16_t*)dres_t, (bf16_t*)dx_t, M, K);
     MBX_LAUNCH_CHECK("rows_lnbwd_t");
     return 0;
 }
@@ -564,13 +628,18 @@ extern "C" int mbx_rows_lnbwd_t(const void* dy, const void* packed, const void* 
 extern "C" int mbx_rows_resid_ln(const void* a, const void* packed, const float* bias, const float* resid, float* y, void* xhat,
                                  float* mean, float* rstd, float eps, int M, int N, int K, void* stream) {
     MBX_CHECK_ARG(a && packed && bias && resid && y && xhat && mean && rstd, "rows_resid_ln: null pointer");
-    MBX_CHECK_ARG(M > 0 && N == RN_N && K >= 512 && K % 256 == 0, "rows_resid_ln: bad shape M=%d N=%d (512) K=%d (%% 256, >= 512)", M, N, K);
-    MBX_CHECK_ARG((size_t)M * RN_N * 4 < ((size_t)1 << 32), "rows_resid_ln: M=%d rows of 2 KiB exceed the 32-bit row offsets of the kernel", M);
+    RN_CHECK_SHAPE("rows_resid_ln");
+    MBX_CHECK_ARG((size_t)M * N * 4 < ((size_t)1 << 32), "rows_resid_ln: M=%d rows of %d bytes exceed the 32-bit row offsets of the kernel", M, N * 4);
     MBX_CHECK_ARG((size_t)M * K * 2 < ((size_t)1 << 32), "rows_resid_ln: a of M=%d x K=%d exceeds the 32-bit lane offsets of the kernel", M, K);
     MBX_CHECK_ARG((const void*)y != (const void*)resid && xhat != a, "rows_resid_ln: y aliases resid (or xhat aliases a): rows past M re-read row M - 1 after it was stored");
-    if (mbx_set_dyn_lds(reinterpret_cast<const void*>(rows_n_resid_ln_kernel), RN_RING + 4 * 8192, "rows_resid_ln")) return 1;
-    hipLaunchKernelGGL(rows_n_resid_ln_kernel, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)a,
-                       (const char*)packed, bias, resid, y, (bf16_t*)xhat, mean, rstd, eps, M, K);
+    const void* kern = N == 512 ? reinterpret_cast<const void*>(rows_n_resid_ln_kernel<16>) : reinterpret_cast<const void*>(rows_n_resid_ln_kernel<8>);
+    if (mbx_set_dyn_lds(kern, RN_RING + 4 * 8192, "rows_resid_ln")) return 1;
+    if (N == 512)
+        hipLaunchKernelGGL(rows_n_resid_ln_kernel<16>, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)a,
+                           (const char*)packed, bias, resid, y, (bf16_t*)xhat, mean, rstd, eps, M, K);
+    else
+        hipLaunchKernelGGL(rows_n_resid_ln_kernel<8>, dim3((M + RN_BM - 1) / RN_BM), dim3(256), RN_RING + 4 * 8192, (hipStream_t)stream, (const bf16_t*)a,
+                           (const char*)packed, bias, resid, y, (bf16_t*)xhat, mean, rstd, eps, M, K);
     MBX_LAUNCH_CHECK("rows_resid_ln");
     return 0;
 }

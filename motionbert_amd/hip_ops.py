@@ -93,9 +93,9 @@ SIGNATURES = {
     'mbx_augment2d': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp] + [_f] * 8 + [_i, C.c_uint64, _vp]),
     'mbx_embed_fwd_tta': (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     'mbx_flip_average': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'mbx_rows_n_pack_bytes': (_sz, [_i]),
+    'mbx_rows_n_pack_bytes': (_sz, [_i, _i]),
     'mbx_rows_lnbwd_t': (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
-    'mbx_rows_n_pack_many': (_i, [_i64p, _i, _i, _vp]),
+    'mbx_rows_n_pack_many': (_i, [_i64p, _i, _i, _i, _vp]),
     'mbx_rows_resid_ln': (_i, [_vp] * 8 + [_f, _i, _i, _i, _vp]),
     'mbx_mfma_probe_ws': (_sz, [_i]),
     'mbx_mfma_probe': (_i, [_vp, _i, _i, C.c_uint, _vp, _vp]),
@@ -357,12 +357,12 @@ class HipOps:
     # ------------------------------------------------------------------ N-resident row-owner GEMM + LayerNorm backward (round 5)
     @staticmethod
     def can_rows_lnbwd(tdtype, cfg) -> bool:
-        """mbx_rows_lnbwd_t exists for bf16, dim_feat = 512 and contraction lengths (3 C, hidden) that are multiples of 256 and >= 512
-        (one ordinary trip of the loop in front of the peeled last one; mlp_ratio 0.5 falls back to the tile kernels)."""
-        return tdtype == torch.bfloat16 and cfg.C == 512 and cfg.hidden % 256 == 0 and cfg.hidden >= 512
+        """mbx_rows_lnbwd_t / mbx_rows_resid_ln exist for bf16, dim_feat 512 (contraction lengths C, 3 C, hidden: multiples of 256, >= 512) and
+        -- round 6 -- dim_feat 256 (MotionBERT-Lite: multiples of 256, >= 256); anything else falls back to the tile kernels."""
+        return (tdtype == torch.bfloat16 and cfg.C in (256, 512) and cfg.hidden % 256 == 0 and cfg.hidden >= (512 if cfg.C == 512 else 256))
 
     def rows_n_pack(self, w_t):
-        """w bf16 [512, K] (the operand of the dX GEMM) in the fragment order of mbx_rows_lnbwd_t / mbx_rows_resid_ln."""
+        """w bf16 [N, K], N = 512 or 256 (the operand of the dX GEMM) in the fragment order of mbx_rows_lnbwd_t / mbx_rows_resid_ln."""
         return self.rows_n_pack_many([w_t])[0]
 
     def rows_n_pack_many(self, ws):
@@ -372,9 +372,11 @@ class HipOps:
         if not ws:
             return []
         dev = ws[0].device
+        N = ws[0].shape[0]
         for w in ws:
-            if w.shape[0] != 512 or w.shape[1] < 512 or w.shape[1] % 256 or w.dtype != torch.bfloat16 or not w.is_contiguous():
-                raise RuntimeError(f'rows_n_pack_many: operand {tuple(w.shape)} {w.dtype} (bf16 [512, K], K % 256 == 0, K >= 512, contiguous)')
+            if w.shape[0] != N or N not in (256, 512) or w.shape[1] < N or w.shape[1] % 256 or w.dtype != torch.bfloat16 or not w.is_contiguous():
+                raise RuntimeError(f'rows_n_pack_many: operand {tuple(w.shape)} {w.dtype} (bf16 [N, K], one N = 256 or 512 for all, K % 256 == 0, '
+                                   f'K >= N, contiguous)')
         # The descriptor table is cached by the operands' offsets from the first one -- stable from step to step when they are views into
         # ONE flat buffer (prep_weights / fold_norm_weights make them so).  Operands of separate allocations get absolute addresses in
         # the key instead: still correct, just a cache entry per set of addresses.
@@ -382,14 +384,14 @@ class HipOps:
         store = ws[0].untyped_storage().data_ptr()
         if any(w.untyped_storage().data_ptr() != store for w in ws):
             base = 0
-        key = ('rnpack', base == 0, tuple((w.data_ptr() - base, w.shape[1]) for w in ws), dev.index)
+        key = ('rnpack', base == 0, N, tuple((w.data_ptr() - base, w.shape[1]) for w in ws), dev.index)
         with self._lock:
             ent = self._desc_cache.get(key)
             if ent is None:
                 offs, off = [], 0
                 for w in ws:
                     offs.append(off)
-                    off += 512 * w.shape[1] * 2
+                    off += N * w.shape[1] * 2
                 self._desc_room('rnpack')
                 ent = dict(desc=torch.tensor([[w.data_ptr() - base, o, w.shape[1]] for w, o in zip(ws, offs)], dtype=torch.int64).to(dev), offs=offs, total=off,
                            max_k=max(w.shape[1] for w in ws))
@@ -398,15 +400,15 @@ class HipOps:
         desc = ent['desc'].clone()
         desc[:, 0] += base
         desc[:, 1] += flat.data_ptr()
-        self._ck(self.lib.mbx_rows_n_pack_many(desc.data_ptr(), len(ws), ent['max_k'], self._stream()))
-        return [flat[o:o + 512 * w.shape[1] * 2] for w, o in zip(ws, ent['offs'])]
+        self._ck(self.lib.mbx_rows_n_pack_many(desc.data_ptr(), len(ws), N, ent['max_k'], self._stream()))
+        return [flat[o:o + N * w.shape[1] * 2] for w, o in zip(ws, ent['offs'])]
 
     def rows_lnbwd_t(self, dy_t, packed, xhat, rstd, dres_t, dx_t):
         """dx_t = T(dres_t + LayerNorm'(dy . w^T)) with both row means taken in the kernel (no row dots from the producers of dy)."""
         M, K = dy_t.shape
         self._ck(self.lib.mbx_rows_lnbwd_t(_p(dy_t), _p(packed), _p(xhat), _p(rstd), _p(dres_t), _p(dx_t), M, dx_t.shape[1], K, self._stream()))
 
-    can_rows_resid_ln = can_rows_lnbwd      # same shape constraints (dim_feat 512; contraction lengths C and hidden)
+    can_rows_resid_ln = can_rows_lnbwd      # same shape constraints (dim_feat 512 or 256; contraction lengths C and hidden)
 
     def rows_resid_ln(self, a_t, packed, bias, resid, y, xhat, mean, rstd, eps):
         """y = resid + a . w^T + bias (fp32) and the plain LayerNorm of its rows (xhat in the operand type, mean, rstd) in one kernel."""

@@ -123,12 +123,17 @@ def test_rows_gemm_rejects_bad_shapes(ops):
         ops.rows_pack_nk(w)                                  # N % 64
 
 
-@pytest.mark.parametrize('M,K', [(128, 512), (4131, 1536), (4131, 1024), (70227, 1536), (33, 512), (2 * 243 * 17, 1024), (129, 1536), (264384, 1024), (300, 768)])
-def test_rows_lnbwd_t(ops, M, K):
+LNBWD_SHAPES = [(128, 512, 512), (4131, 1536, 512), (4131, 1024, 512), (70227, 1536, 512), (33, 512, 512), (2 * 243 * 17, 1024, 512), (129, 1536, 512),
+                (264384, 1024, 512), (300, 768, 512),
+                # dim_feat 256 (MotionBERT-Lite, round 6): dX of qkv (K = 768) and of fc1 (K = 1024), one-trip and ragged cases
+                (128, 256, 256), (4131, 768, 256), (4131, 1024, 256), (33, 512, 256), (129, 768, 256), (70227, 768, 256), (264384, 1024, 256)]
+
+
+@pytest.mark.parametrize('M,K,N', LNBWD_SHAPES)
+def test_rows_lnbwd_t(ops, M, K, N):
     """mbx_rows_lnbwd_t (csrc/gemm_rows_n.hip): dX GEMM of a folded (LayerNorm -> Linear) pair + LayerNorm backward with the row means
     taken from the accumulators, against the torch restatement (fp32 product of the same bf16 operands, exact means) and -- the
     identity the kernel rests on -- against LayerNorm's backward by autograd on the same dxhat."""
-    N = 512
     dy = rnd(M, K, seed=M + 1, dtype=BF, scale=0.5)
     w = rnd(N, K, seed=M + 2, dtype=BF, scale=0.05)
     x = rnd(M, N, seed=M + 3) * (0.5 + rnd(M, 1, seed=M + 4).abs()) + 0.3 * rnd(M, 1, seed=M + 5)
@@ -140,23 +145,28 @@ def test_rows_lnbwd_t(ops, M, K):
     ops.rows_lnbwd_t(dy, ops.rows_n_pack(w), xhat, rstd, dres, out)
     ref = torch.empty_like(out)
     MockOps().rows_lnbwd_t(dy, w, xhat, rstd, dres, ref)
-    check(f'rows_lnbwd_t.{M}x{K}', out, ref, 4e-3)
+    check(f'rows_lnbwd_t.{M}x{K}x{N}', out, ref, 4e-3)
     # the branch alone (dx - dres) against autograd through the plain normalisation of the same rows, with d(xhat) = dy . w^T in fp32:
     # the bf16 xhat the kernel reads differs from the exact one by its rounding, hence 1e-2
     if M <= 8192:
         xg = x.clone().requires_grad_(True)
         xh = (xg - xg.mean(-1, keepdim=True)) * torch.rsqrt(xg.var(-1, unbiased=False, keepdim=True) + 1e-6)
         xh.backward(dy.float() @ w.float().t())
-        check(f'rows_lnbwd_t.vs_autograd.{M}x{K}', out.float() - dres.float(), xg.grad, 2e-2)
+        check(f'rows_lnbwd_t.vs_autograd.{M}x{K}x{N}', out.float() - dres.float(), xg.grad, 2e-2)
     assert torch.isfinite(out.float()).all()
 
 
-@pytest.mark.parametrize('M,K', [(128, 512), (4131, 512), (4131, 1024), (70227, 512), (33, 1024), (2 * 243 * 17, 512), (129, 1536), (264384, 1024), (300, 768)])
-def test_rows_resid_ln(ops, M, K):
+RESID_SHAPES = [(128, 512, 512), (4131, 512, 512), (4131, 1024, 512), (70227, 512, 512), (33, 1024, 512), (2 * 243 * 17, 512, 512), (129, 1536, 512),
+                (264384, 1024, 512), (300, 768, 512),
+                # dim_feat 256 (MotionBERT-Lite, round 6): proj (K = 256: the single, peeled trip) and fc2 (K = 1024)
+                (128, 256, 256), (4131, 256, 256), (4131, 1024, 256), (33, 512, 256), (129, 768, 256), (70227, 256, 256), (264384, 1024, 256)]
+
+
+@pytest.mark.parametrize('M,K,N', RESID_SHAPES)
+def test_rows_resid_ln(ops, M, K, N):
     """mbx_rows_resid_ln (csrc/gemm_rows_n.hip): y = resid + a . w^T + bias in fp32 and the plain LayerNorm of its rows (xhat, mean, rstd)
     from the same registers, against the torch restatement and against what the product ran before -- the residual epilogue of
     mbx_gemm_nt followed by mbx_layernorm_fwd; rows with a large common offset included (the statistics are two-pass)."""
-    N = 512
     a = rnd(M, K, seed=M + 1, dtype=BF, scale=0.7)
     w = rnd(N, K, seed=M + 2, dtype=BF, scale=0.05)
     bias = rnd(N, seed=M + 3, scale=0.3)
@@ -166,7 +176,7 @@ def test_rows_resid_ln(ops, M, K):
     g, r, o = mk(), mk(), mk()
     ops.rows_resid_ln(a, ops.rows_n_pack(w), bias, resid, *g, 1e-6)
     MockOps().rows_resid_ln(a, w, bias, resid, *r, 1e-6)
-    tag = f'{M}x{K}'
+    tag = f'{M}x{K}x{N}'
     for name, u, v, tol in zip(('y', 'xhat', 'mean', 'rstd'), g, r, (2e-6, 4e-3, 1e-5, 1e-5)):
         assert torch.isfinite(u.float()).all(), name
         check(f'rows_resid_ln.{name}.{tag}', u, v, tol)
@@ -182,7 +192,7 @@ def test_rows_resid_ln_rejects_bad_shapes(ops):
     pk = ops.rows_n_pack(w)
     f = lambda *s: torch.empty(*s, device=DEV)
     with pytest.raises(RuntimeError):
-        ops.rows_resid_ln(a, pk, f(256), f(64, 256), f(64, 256), torch.empty(64, 256, device=DEV, dtype=BF), f(64), f(64), 1e-6)      # N != 512
+        ops.rows_resid_ln(a, pk, f(128), f(64, 128), f(64, 128), torch.empty(64, 128, device=DEV, dtype=BF), f(64), f(64), 1e-6)      # N not 256 / 512
     with pytest.raises(RuntimeError):
         ops.rows_resid_ln(rnd(64, 384, seed=3, dtype=BF), pk, f(512), f(64, 512), f(64, 512), torch.empty(64, 512, device=DEV, dtype=BF), f(64), f(64), 1e-6)   # K % 256
 
@@ -244,4 +254,6 @@ def test_rows_lnbwd_t_rejects_bad_shapes(ops):
     with pytest.raises(RuntimeError):
         ops.rows_n_pack(w)                                   # K % 256
     with pytest.raises(RuntimeError):
-        ops.rows_n_pack(rnd(256, 512, seed=3, dtype=BF))     # N != 512
+        ops.rows_n_pack(rnd(128, 512, seed=3, dtype=BF))     # N not 256 / 512
+    with pytest.raises(RuntimeError):
+        ops.rows_n_pack(rnd(512, 256, seed=4, dtype=BF))     # N = 512 needs K >= 512

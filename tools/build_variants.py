@@ -26,7 +26,7 @@ def main():
 
     def cc(src):
         o = os.path.join(obj, src.replace('.hip', '.o'))
-        subprocess.run([hipcc] + B.FLAGS + extra + ['-c', os.path.join(B.CSRC, src), '-o', o], check=True)
+        subprocess.run([hipcc] + B.flags_for(src) + extra + ['-c', os.path.join(B.CSRC, src), '-o', o], check=True)
         return o
     with ThreadPoolExecutor(max_workers=len(B.SOURCES)) as ex:
         objs = list(ex.map(cc, B.SOURCES))
