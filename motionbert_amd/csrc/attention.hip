@@ -869,39 +869,28 @@ __global__ __launch_bounds__(1024, 1) void attn_bwd_fused_kernel(const bf16_t* _
     const T* obase = o + P.tok0 * C + (size_t)P.h * HD;
     if (STATS) fill_stat_vec<HD>(vec, st_rsum, st_bias, C, P.h, tid, 1024);
 
-    // ---- the loads of the per-query statistics (dO . O, lse: four lanes per row, KP <= 256 rows = one pass of the 1024 threads) go
-    // out FIRST, so that their latency runs under the tile fill instead of after it (MBX_ATTN_STAT_EARLY=0: the old order) ----
-constexpr int MBX_ATTN_STAT_EARLY = 1;
-    const int sr = tid >> 2, spart = tid & 3;
-    uint2 sx[HD / 16], sy[HD / 16];
-    float sl = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD / 16; ++d) { sx[d] = make_uint2(0u, 0u); sy[d] = make_uint2(0u, 0u); }
-#define ATTN_STAT_LOAD()                                                                                   \
-    if (sr < P.L) {                                                                                        \
-        const T* a_ = dobase + (size_t)sr * ostride + spart * (HD / 4);                                    \
-        const T* b_ = obase + (size_t)sr * ostride + spart * (HD / 4);                                     \
-        _Pragma("unroll") for (int d = 0; d < HD / 16; ++d) {                                              \
-            sx[d] = *reinterpret_cast<const uint2*>(a_ + 4 * d);                                           \
-            sy[d] = *reinterpret_cast<const uint2*>(b_ + 4 * d);                                           \
-        }                                                                                                  \
-        sl = lse[(P.tok0 + (size_t)sr * P.tstep) * H + P.h];                                               \
-    }
-    if (MBX_ATTN_STAT_EARLY && !(MBX_ATTN_DBG & 4)) { ATTN_STAT_LOAD(); }
-    // ---- stage the four tiles: 16-byte chunks, all loads of a pass in flight before the first LDS store ----
+    // ---- stage the four tiles: 16-byte chunks, all loads of a pass in flight before the first LDS store.  The per-query statistics
+    // come out of the same loads (round 6): delta = dO . O needs the dO chunk the thread fetches for the tile anyway, so it fetches the
+    // matching chunk of O beside it and the CH lanes of a row reduce their 8-element dots on the VALU; lane ch = 0 also fetches lse.
+    // (Rounds 2-5 read dO a second time, four lanes per row: 62 instead of 31 KiB of statistics traffic per problem, on a fill that
+    // runs at the CU's ~24 KB/us -- profiles/r06_attn_trace.txt.)  KP CH <= 2048: one pass, two chunks per thread. ----
     for (int i0 = tid; i0 < KP * CH; i0 += 2048) {
-        uint4 v[2][4];
+        uint4 v[2][4], vo[2];
+        float sl[2] = {0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int idx = i0 + u * 1024, row = idx / CH, ch = idx % CH;
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[u][t] = make_uint4(0u, 0u, 0u, 0u);
+            vo[u] = make_uint4(0u, 0u, 0u, 0u);
             if (idx < KP * CH && row < P.L && !(MBX_ATTN_DBG & 4)) {
                 const T* r3 = qbase + (size_t)row * rstride + ch * 8;
                 v[u][0] = *reinterpret_cast<const uint4*>(r3);
                 v[u][1] = *reinterpret_cast<const uint4*>(r3 + C);
                 v[u][2] = *reinterpret_cast<const uint4*>(r3 + 2 * C);
                 v[u][3] = *reinterpret_cast<const uint4*>(dobase + (size_t)row * ostride + ch * 8);
+                vo[u] = *reinterpret_cast<const uint4*>(obase + (size_t)row * ostride + ch * 8);
+                if (ch == 0) sl[u] = lse[(P.tok0 + (size_t)row * P.tstep) * H + P.h];
             }
         }
 #pragma unroll
@@ -915,24 +904,22 @@ constexpr int MBX_ATTN_STAT_EARLY = 1;
                 *reinterpret_cast<uint4*>(dot_ + off) = v[u][3];
             }
         }
-    }
-    AT_TS(1);
-    // ---- per-query statistics: four lanes per row, each HD/4 of the d range, quad-reduced on the VALU ----
-    if (!MBX_ATTN_STAT_EARLY) { ATTN_STAT_LOAD(); }
-#undef ATTN_STAT_LOAD
-    if (sr < KP) {
-        float dl = 0.f;
+        AT_TS(1);
 #pragma unroll
-        for (int d = 0; d < HD / 16; ++d) {
-            float x[4], y[4];
-            Raw4b::unpack(sx[d], x); Raw4b::unpack(sy[d], y);
+        for (int u = 0; u < 2; ++u) {      // (every lane takes part in the DPP steps: rows past KP carry zeros)
+            const int idx = i0 + u * 1024, row = idx / CH, ch = idx % CH;
+            float x[4], y[4], dl = 0.f;
+            Raw4b::unpack(make_uint2(v[u][3].x, v[u][3].y), x); Raw4b::unpack(make_uint2(vo[u].x, vo[u].y), y);
             dl = fmaf(x[0], y[0], fmaf(x[1], y[1], fmaf(x[2], y[2], fmaf(x[3], y[3], dl))));
-        }
-        dl += dpp_mov<0xB1>(dl, dl);    // quad_perm [1,0,3,2]
-        dl += dpp_mov<0x4E>(dl, dl);    // quad_perm [2,3,0,1]
-        if (spart == 0) {
-            lse_s[sr] = sl * 1.44269504088896341f;   // base-2 units: p = 2^(s*c2 - lse2)
-            del_s[sr] = dl;
+            Raw4b::unpack(make_uint2(v[u][3].z, v[u][3].w), x); Raw4b::unpack(make_uint2(vo[u].z, vo[u].w), y);
+            dl = fmaf(x[0], y[0], fmaf(x[1], y[1], fmaf(x[2], y[2], fmaf(x[3], y[3], dl))));
+            dl += dpp_mov<0xB1>(dl, dl);                      // quad_perm [1,0,3,2]
+            dl += dpp_mov<0x4E>(dl, dl);                      // quad_perm [2,3,0,1]
+            if (CH == 8) dl += dpp_mov<0x141>(dl, dl);        // row_half_mirror: the other quad of the row's eight lanes
+            if (ch == 0 && idx < KP * CH) {
+                lse_s[row] = sl[u] * 1.44269504088896341f;    // base-2 units: p = 2^(s*c2 - lse2)
+                del_s[row] = dl;
+            }
         }
     }
     __syncthreads();
