@@ -1455,12 +1455,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     for (int c = 0; c < nc; ++c) {
         const int vc = c_beg + c;
         U_READ(stage, vc);
-        // own share of chunk c+1 landed (c+2 may fly); the fragments have arrived (asm reads: nothing may touch them earlier)
-        if (nc - 1 - c >= 2) {
-            TR_WAIT6("vmcnt(4) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
-        } else {
-            TR_WAIT6("vmcnt(0) lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
-        }
+        // own share of chunk c+1 landed (c+2 may fly); the fragments have arrived (asm reads: nothing may touch them earlier).
+        // (Round 6: the vmcnt wait stands alone, ONE statement carries the data dependence of the first six fragments.  With the two
+        // forms "vmcnt(4) lgkmcnt(0)" / "vmcnt(0) lgkmcnt(0)" in an if / else the compiler gave the statement's tied operands other
+        // registers than the reads had written and copied the six fragments over -- 12 v_mov_b64 per chunk at the end of the read
+        // phase, the phase that paces the kernel; in the tail branch it placed the copies in FRONT of the wait, i.e. it copied registers
+        // with their reads in flight, harmless only because issuing the other twelve reads takes longer than the first twelve to land.)
+        if (nc - 1 - c >= 2) WAIT_VMCNT(4); else WAIT_VMCNT(0);
+        TR_WAIT6("lgkmcnt(0)", fy[0][0], fy[0][1], fy[0][2], fy[0][3], fa[0][0], fa[0][1]);
         TR_WAIT6("lgkmcnt(0)", fy[1][0], fy[1][1], fy[1][2], fy[1][3], fa[1][0], fa[1][1]);
         U_FIX(vc);
         U_DB_SHARE(vc);      // at the end of the read phase (behind the MFMAs of the other phase it measured the same: 0.566 vs 0.563 ms)
