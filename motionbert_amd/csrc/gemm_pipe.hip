@@ -1314,6 +1314,9 @@ static constexpr int U_TILE = U_BMS * 512, U_STAGE = 2 * U_TILE;   // 16 KiB per
 
 // X3 (precision 'bf16x3'): dW = dY_hi^T A_hi + dY_hi^T A_lo + dY_lo^T A_hi, the three passes laid end to end as ONE token
 // stream of 3 * ceil(M / 32) chunks (pass p: tokens of (dY_hi, A_hi), (dY_hi, A_lo), (dY_lo, A_hi)); db sums passes 0 and 2.
+#ifdef MBX_TN_TRACE
+__device__ long long* g_tn_trace;
+#endif
 template <bool X3>
 __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A,
                                                                  const bf16_t* __restrict__ dY_lo, const bf16_t* __restrict__ A_lo,
@@ -1452,6 +1455,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
     } while (0)
 #define U_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
     int stage = 0;
+#ifdef MBX_TN_TRACE     // diagnostic builds (tools/tn_trace.py): cycles of wave 0 / wave 4 of every workgroup in the four parts of a chunk, summed
+    long long tt[4] = {0, 0, 0, 0}, t0 = (long long)__builtin_readcyclecounter();
+#define TN_TS(k_) do { const long long t1_ = (long long)__builtin_readcyclecounter(); tt[k_] += t1_ - t0; t0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TN_TS(k_) do { } while (0)
+#endif
     for (int c = 0; c < nc; ++c) {
         const int vc = c_beg + c;
         U_READ(stage, vc);
@@ -1466,12 +1475,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe256_kernel(const bf16_t* _
         TR_WAIT6("lgkmcnt(0)", fy[1][0], fy[1][1], fy[1][2], fy[1][3], fa[1][0], fa[1][1]);
         U_FIX(vc);
         U_DB_SHARE(vc);      // at the end of the read phase (behind the MFMAs of the other phase it measured the same: 0.566 vs 0.563 ms)
+        TN_TS(0);
         U_BARRIER();
+        TN_TS(1);
         if (c + MBX_TN_AHEAD < nc) U_ISSUE(vc + MBX_TN_AHEAD, (stage + MBX_TN_AHEAD) & 3);
         U_MMA();
+        TN_TS(2);
         U_BARRIER();
+        TN_TS(3);
         stage = (stage + 1) & 3;
     }
+#ifdef MBX_TN_TRACE
+    if (g_tn_trace != nullptr && (tid == 0 || tid == 256)) {
+        long long* const tr = g_tn_trace + ((size_t)blockIdx.x * 2 + (tid == 256)) * 5;
+        tr[0] = tt[0]; tr[1] = tt[1]; tr[2] = tt[2]; tr[3] = tt[3]; tr[4] = nc;
+    }
+#endif
+#undef TN_TS
     if (!trailing) __builtin_amdgcn_s_barrier();
 #undef U_BARRIER
 #undef U_DB_SHARE
@@ -1541,6 +1561,12 @@ int mbx_launch_gemm_tn_pipe(const void* dy, const void* a, float* dw, float* db,
         const size_t shm256 = 4 * U_STAGE;
         const int ntiles256 = ntn * ntk, groups256 = (splits + 7) / 8;
         if (set_lds_attr(gemm_tn_pipe256_kernel<false>, shm256, "gemm_tn_pipe256")) return 1;
+#ifdef MBX_TN_TRACE
+        {
+            static long long* const tb = [] { const char* e = getenv("MBX_TRACE_BUF"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
+            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tn_trace), &tb, sizeof(tb), 0, hipMemcpyHostToDevice, s);
+        }
+#endif
         hipLaunchKernelGGL(gemm_tn_pipe256_kernel<false>, dim3(8 * groups256 * ntiles256), dim3(512), shm256, s, (const bf16_t*)dy,
                            (const bf16_t*)a, (const bf16_t*)nullptr, (const bf16_t*)nullptr, part_w, part_b, M, N, K, ntk, ntiles256,
                            splits, cps);
