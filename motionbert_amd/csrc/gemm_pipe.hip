@@ -1530,10 +1530,21 @@ static int tnp_splits(int M, int N, int K, bool x3 = false) {
     const int nchunks = (x3 ? 3 : 1) * (big ? (M + U_BMS - 1) / U_BMS : (M + T_BMS - 1) / T_BMS);
     // one workgroup per CU: the launch should be an exact number of 256-workgroup waves (measured: 288 blocks
     // cost 1.10 ms where 768 cost 0.77 ms on the QKV weight gradient) and a multiple of the 8 XCDs
-    int s = ((512 / tiles + 7) / 8) * 8;
+    int s = 0;
     for (int w = 1; w <= 4; ++w)
         if ((256 * w) % tiles == 0 && ((256 * w) / tiles) % 8 == 0 && (256 * w) / tiles <= 128) { s = (256 * w) / tiles; break; }
-    if (s > 128) s = 128;
+    if (s == 0 && big) {
+        // (round 6) no split count <= 128 gives whole rounds: 1 or 3 output tiles -- MotionBERT-Lite's dW of proj [256, 256] and of qkv
+        // [768, 256], which ran on 128 (half a round) and 384 workgroups (a round and a half).  Pick the multiple of 8 up to 256 that
+        // minimises  rounds x chunks per split x ~1 us  +  the partials' round trip (written here, read by the column sum) at ~4 TB/s
+        double best = 1e30;
+        for (int c = 8; c <= 256; c += 8) {
+            const int rounds = (tiles * c + 255) / 256, cps = (nchunks + c - 1) / c;
+            const double cost = (double)rounds * cps + (double)c * N * K * 8.0 / 4e6;
+            if (cost < best) { best = cost; s = c; }
+        }
+    }
+    if (s == 0) { s = ((512 / tiles + 7) / 8) * 8; if (s > 128) s = 128; }
     if (s > nchunks) s = nchunks;
     if (s < 1) s = 1;
     return s;
